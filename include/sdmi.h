@@ -1,0 +1,128 @@
+/* sdmi.h - C ABI of libsdmi355.so: gfx950 (MI355X) kernels for the SD-2.x inpainting hot path.
+ *
+ * The reference (ccharest93/Stable-Diffusion, /root/reference) has no FFI: its operator layer is
+ * torch.nn / torch.nn.functional plus xformers.ops.memory_efficient_attention.  Each entry point
+ * below names the reference operator call(s) it replaces (file:line relative to /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SDMI_E* code otherwise; sdmi_last_error()
+ *     returns a thread-local message.  Nothing throws, exits or synchronises the device.
+ *   - all pointers are DEVICE pointers owned by the caller; the library allocates nothing.
+ *     Scratch space comes in through explicit workspace arguments.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.
+ *   - activations: "NHWC bf16" = [N][H*W][C] row-major with row stride ld (elements, multiple of 8);
+ *     this is also the (B, tokens, C) layout of the transformer blocks, so no permutes exist.
+ *   - packed weights: bf16 [N_out][K], K contiguous (for a 3x3 conv K = (ky*3+kx)*Cin + c).
+ */
+#ifndef SDMI_H
+#define SDMI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDMI_OK 0
+#define SDMI_EINVAL (-1)   /* bad argument / unsupported shape */
+#define SDMI_ELAUNCH (-2)  /* HIP launch error */
+
+/* epilogue / mode flags */
+#define SDMI_F_BIAS 1u      /* + bias[n]                       (fp32 [N])                    */
+#define SDMI_F_ROWBIAS 2u   /* + rowbias[sample(m)*ldrb + n]   (fp32, row stride ldrb; timestep-emb add) */
+#define SDMI_F_RESIDUAL 4u  /* + residual[m][n]                (bf16, stride ldr)            */
+#define SDMI_F_GEGLU 8u     /* out[m][j] = x*gelu(gate), weights packed by sdmi_pack_linear(geglu=1) */
+#define SDMI_F_OUT_NCHW_F32 16u /* store fp32 NCHW instead of bf16 NHWC (module boundary)   */
+#define SDMI_F_UPSAMPLE2X 32u   /* conv: input is read through a nearest 2x upsample gather  */
+#define SDMI_F_SILU 64u     /* groupnorm_apply / small linear: SiLU                           */
+#define SDMI_F_OUT_F32 128u /* gemm: store fp32 row-major (ldc in elements) instead of bf16  */
+
+int sdmi_version(void);
+const char* sdmi_last_error(void);
+
+/* ---- weight pre-pack (run once per parameter, after load_state_dict) ---------------------- */
+/* fp32 OIHW (Cout,Cin,3,3) -> bf16 [Cout][9][Cin].  replaces nothing: layout change for sdmi_conv3x3. */
+int sdmi_pack_conv3x3(const float* w_oihw, void* w_packed, int cout, int cin, void* stream);
+/* fp32 [N][K] (nn.Linear weight or 1x1 conv) -> bf16 [N][K]; geglu=1 interleaves the value/gate rows
+ * of GEGLU.proj in 16-row groups so that x*gelu(gate) is lane-local in the GEMM epilogue. */
+int sdmi_pack_linear(const float* w, void* w_packed, int n, int k, int geglu, void* stream);
+
+/* ---- layout at the module boundary (reference tensors are NCHW fp32: SURVEY 8(b)) ---------- */
+int sdmi_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int hw, int ldd, void* stream);
+int sdmi_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int hw, int lds, void* stream);
+/* fp32 [rows][cols] -> bf16 [rows][ld]  (text context (B,77,1024) entering to_k / to_v) */
+int sdmi_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int ld, void* stream);
+
+/* ---- GroupNorm(32) (+SiLU): nn.GroupNorm + nn.SiLU at layers/ResBlock.py:65-66,:72-73; Unet.py:104-106;
+ *      AutoencoderKL.py:193-194; layers/SpatialTransformer.py:134,:212 ----------------------- */
+/* bytes of workspace sdmi_groupnorm_stats needs */
+int64_t sdmi_groupnorm_ws_bytes(int n, int hw, int c);
+/* pass 1: per-(sample,group) statistics -> scale_shift fp32 [N][C][2] = {gamma*rstd, beta-mean*gamma*rstd} */
+int sdmi_groupnorm_stats(const void* x, int n, int hw, int c, int ldx, int groups, const float* gamma,
+                         const float* beta, float eps, float* scale_shift, void* ws, void* stream);
+/* pass 2: y = act(x*scale+shift), bf16 NHWC -> bf16 NHWC (flags: SDMI_F_SILU) */
+int sdmi_groupnorm_apply(const void* x, int ldx, const float* scale_shift, void* y, int ldy, int n, int hw, int c,
+                         uint32_t flags, void* stream);
+
+/* ---- LayerNorm: nn.LayerNorm at layers/SpatialTransformer.py:177-184 ----------------------- */
+int sdmi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
+                   int rows, int c, void* stream);
+
+/* ---- 3x3 implicit-GEMM convolution on MFMA: nn.Conv2d k=3 at layers/ResBlock.py:67,:74 (pad 1),
+ *      Downsample :36-37 (explicit pad + stride 2), Upsample :17-19 (nearest 2x + pad + conv, flag
+ *      SDMI_F_UPSAMPLE2X), Unet.py:107, AutoencoderKL.py:172; epilogue fuses the conv bias, the
+ *      timestep-embedding add of layers/ResBlock.py:70 (SDMI_F_ROWBIAS) and the skip add of :76
+ *      (SDMI_F_RESIDUAL).
+ *   x: NHWC bf16 (n,h,w,cin) stride ldx; hout/wout/pad_t/pad_l/stride describe the geometry AFTER the
+ *   optional 2x upsample (input pixel = (oy*stride+ky-pad_t, ox*stride+kx-pad_l), zero outside).   */
+int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout,
+                 int hout, int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias,
+                 int ldrb, const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* stream);
+
+/* ---- first-layer conv with tiny Cin reading the caller's NCHW fp32 tensor directly:
+ *      Unet.py:49 (9->320), AutoencoderKL.py:136 (4->512), :61 (3->128).  w is the fp32 OIHW weight. */
+int sdmi_conv3x3_in(const float* x_nchw, int n, int cin, int h, int w, const float* w_oihw, const float* bias,
+                    int cout, void* out, int ldc, void* stream);
+
+/* ---- GEMM out[M][N] = A[M][K] * W[N][K]^T (+epilogue): nn.Linear and 1x1 nn.Conv2d at
+ *      layers/SpatialTransformer.py:22-26 (GEGLU), :62-66, :110-129, :199, :204; layers/ResBlock.py:62;
+ *      AutoencoderKL.py:203-204.  batch>1 runs independent problems with element strides sa/sw/sc
+ *      (used for the VAE single-head attention score / value products).  rows_per_sample maps a row
+ *      to its sample for SDMI_F_ROWBIAS. */
+int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
+              int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
+              int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* stream);
+
+/* ---- skinny linear for M <= 64 rows: Unet.time_embed (Unet.py:41-45) and every ResBlock.emb_proj
+ *      (layers/ResBlock.py:70) batched into one launch. x fp32 [M][K]; w bf16 [N][K]; out fp32 [M][N];
+ *      SDMI_F_SILU applies SiLU to x on load. */
+int sdmi_linear_small_m(const float* x, const void* w, const float* bias, float* out, int m, int n, int k,
+                        uint32_t flags, void* stream);
+
+/* ---- sinusoidal timestep embedding: Unet.py:7-25.  freqs fp32 [half] is the host-computed table
+ *      exp(-ln(1e4) i/half); out fp32 [M][2*half] = [cos | sin]. */
+int sdmi_timestep_embedding(const int64_t* t, const float* freqs, float* out, int m, int half, void* stream);
+
+/* ---- fused flash attention, head_dim 64: xformers.ops.memory_efficient_attention + the head
+ *      split/merge reshapes at layers/SpatialTransformer.py:76-95.  q/k/v/o are bf16 token-major
+ *      (B, tokens, heads*64) views with row strides ld* and per-batch element strides s*; head h lives
+ *      in columns [64h, 64h+64).  o = softmax(q k^T * scale) v. */
+int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
+                   int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv,
+                   float scale, void* stream);
+
+/* ---- row softmax (VAE single-head d=512 attention, layers/SpatialTransformer.py:151, runs as
+ *      score GEMM -> this -> value GEMM).  x fp32 [rows][ldx] -> y bf16 [rows][ldy], y = softmax(x*scale). */
+int sdmi_softmax_rows(const float* x, int ldx, void* y, int ldy, int rows, int cols, float scale, void* stream);
+
+/* ---- fused classifier-free guidance + DDIM update: LatentDiffusionInpainting.py:198-212.
+ *   eps fp32 NCHW (2b,4,h,w) = [uncond | cond]; x, noise fp32 (b,4,h,w); coef = {sqrt_one_minus_at, a_t,
+ *   a_prev, sigma_t} as the fp32 values torch.full() would hold; writes x_out (may alias x), pred_x0
+ *   (optional, may be NULL) and, when xc_out != NULL, copies x_out into channels [0,4) of both CFG halves
+ *   of the next UNet input xc (2b, xc_channels, h, w). */
+int sdmi_cfg_ddim_step(const float* eps, const float* x, const float* noise, float guidance, float s1m, float a_t,
+                       float a_prev, float sigma, float temperature, float* x_out, float* pred_x0, float* xc_out,
+                       int xc_channels, int b, int chw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,67 @@
+"""ctypes binding of include/sdmi.h (libsdmi355.so).
+
+The library is the product path: if it is missing this module raises at first use - there is no
+PyTorch / CPU fallback (a silent fallback would void every parity claim).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdmi355.so")
+
+# flags (sdmi.h)
+F_BIAS, F_ROWBIAS, F_RESIDUAL, F_GEGLU, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_SILU, F_OUT_F32 = 1, 2, 4, 8, 16, 32, 64, 128
+
+_vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+
+# name -> (restype, argtypes); mirrors include/sdmi.h declaration by declaration
+PROTOTYPES = {
+    "sdmi_version": (_i, []),
+    "sdmi_last_error": (C.c_char_p, []),
+    "sdmi_pack_conv3x3": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sdmi_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sdmi_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sdmi_nhwc_bf16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sdmi_f32_to_bf16_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sdmi_groupnorm_ws_bytes": (_i64, [_i, _i, _i]),
+    "sdmi_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "sdmi_groupnorm_apply": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _u32, _vp]),
+    "sdmi_layernorm": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "sdmi_conv3x3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp]),
+    "sdmi_conv3x3_in": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "sdmi_gemm": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp]),
+    "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
+    "sdmi_timestep_embedding": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),
+    "sdmi_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
+    "sdmi_cfg_ddim_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class SdmiError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libsdmi355.so and bind every symbol of sdmi.h; raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdmiError("libsdmi355.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C stable-diffusion_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise SdmiError(sdmi_last_error()) on a non-zero code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise SdmiError("%s -> %d: %s" % (name, rc, lib.sdmi_last_error().decode()))

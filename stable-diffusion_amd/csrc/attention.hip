@@ -1,0 +1,181 @@
+// attention.hip - fused flash-style attention forward, head_dim 64, bf16 in/out, fp32 softmax state.
+//
+// Replaces xformers.ops.memory_efficient_attention(q,k,v) and the head split/merge copies around it
+// (layers/SpatialTransformer.py:76-95): o = softmax(q k^T * scale) v, no mask, no dropout.  q/k/v/o are
+// read and written in place as (B, tokens, heads*64) views, so nothing is permuted or made contiguous.
+//
+// Structure (gfx950): block = 4 waves, each wave owns 32 query rows; KV tiles of 64 keys are staged
+// global -> registers -> LDS (the loads of tile t+1 are in flight while tile t is computed).
+//   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with K rows as the A operand (ds_read_b128, XOR-swizzled rows) and
+//                 the wave's Q fragment (registers, loaded once) as B: the accumulator then has the QUERY on
+//                 the lane and the keys in registers, so the online softmax (row max / sum) is lane-local
+//                 plus one cross-half exchange, and P (bf16) is directly the B operand of the next product.
+//   O^T += V^T P^T  V is stored row-major [key][d] and read through ds_read_b64_tr_b16 (hardware
+//                 transpose), the k order inside each 16-key step following the accumulator's row order.
+#include "common.h"
+
+struct AttnParams {
+  const u16* q; const u16* k; const u16* v; u16* o;
+  long long sq, sk, sv, so;
+  int ldq, ldk, ldv, ldo;
+  int nq, nkv;
+  float scale_log2;
+};
+
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+__device__ __forceinline__ int v_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 1) << 2)) << 3); }
+
+__global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) u16 sK[64 * 64];
+  __shared__ __attribute__((aligned(16))) u16 sV[64 * 64];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, bz = blockIdx.z;
+  const u16* Q = p.q + (long long)bz * p.sq + head * 64;
+  const u16* K = p.k + (long long)bz * p.sk + head * 64;
+  const u16* V = p.v + (long long)bz * p.sv + head * 64;
+  u16* O = p.o + (long long)bz * p.so + head * 64;
+
+  const int qrow = blockIdx.x * 128 + wv * 32 + r;
+  const int qrc = qrow < p.nq ? qrow : p.nq - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
+
+  // staging: 64 rows x 8 chunks of 16 B per tile and operand; thread -> (row = t>>3 (+32), chunk = t&7)
+  const int chunk = t & 7, r0 = t >> 3;
+  uint4 rk[2], rv[2];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = kv0 + r0 + 32 * i;
+      const bool ok = key < p.nkv;
+      rk[i] = ok ? *(const uint4*)(K + (long long)key * p.ldk + chunk * 8) : zero4;
+      rv[i] = ok ? *(const uint4*)(V + (long long)key * p.ldv + chunk * 8) : zero4;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *(uint4*)&sK[k_off(r0 + 32 * i, chunk)] = rk[i];
+      *(uint4*)&sV[v_off(r0 + 32 * i, chunk)] = rv[i];
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+  float mrun = -1e30f, lrun = 0.f;
+
+  // transposed-read lane constants: 16-lane group g -> (hh, dblk); inside the group lane i = 4*tq + tp
+  const int dblk = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+
+  const int ntiles = (p.nkv + 63) / 64;
+  load_tile(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int kv0 = tile * 64;
+    store_tile();
+    __syncthreads();
+    if (tile + 1 < ntiles) load_tile(kv0 + 64);
+
+    // ---- S^T[key][q] ----
+    f32x16 s[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 a = *(const bf16x8*)&sK[k_off(32 * kt2 + r, 2 * ks + hh)];
+        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kt2], 0, 0, 0);
+      }
+    // ---- online softmax, query on the lane ----
+    const bool tail = kv0 + 64 > p.nkv;
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = s[kt2][i] * p.scale_log2;
+        if (tail) {
+          const int key = kv0 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (key >= p.nkv) v = -1e30f;
+        }
+        s[kt2][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(mrun, mx);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+    mrun = mnew;
+    float rs = 0.f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = __builtin_amdgcn_exp2f(s[kt2][i] - mnew);
+        s[kt2][i] = e;
+        rs += e;
+      }
+    lrun = lrun * alpha + rs;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+
+    // ---- O^T[d][q] += V^T[d][key] P^T[key][q] ----
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[kt2][8 * s2 + j];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int c = 4 * dt + 2 * dblk + (tp >> 1);
+          const int row0 = 32 * kt2 + 16 * s2 + 4 * hh + tq;
+          const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0, c) + 4 * (tp & 1)));
+          const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0 + 8, c) + 4 * (tp & 1)));
+          union { struct { short4_t a, b; } h; bf16x8 v; } u;
+          u.h.a = lo;
+          u.h.b = hi;
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pb, oacc[dt], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+  }
+
+  const float ltot = lrun + __shfl_xor(lrun, 32);
+  const float inv = 1.0f / ltot;
+  if (qrow < p.nq) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * hh;
+        const uint2 o2 = make_uint2(pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
+                                    pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv));
+        *(uint2*)(O + (long long)qrow * p.ldo + d) = o2;
+      }
+  }
+}
+
+extern "C" int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
+                              int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv,
+                              float scale, void* stream) {
+  SDMI_REQUIRE(q && k && v && o, "attention: null pointer");
+  SDMI_REQUIRE(batch > 0 && heads > 0 && nq > 0 && nkv > 0, "attention: bad shape");
+  SDMI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: row strides must be multiples of 8");
+  SDMI_REQUIRE(ldq >= heads * 64 && ldk >= heads * 64 && ldv >= heads * 64 && ldo >= heads * 64, "attention: row stride < heads*64");
+  SDMI_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)o & 7) == 0, "attention: pointer alignment");
+  SDMI_REQUIRE(sq % 8 == 0 && sk % 8 == 0 && sv % 8 == 0 && so % 4 == 0, "attention: batch strides must keep alignment");
+  SDMI_REQUIRE(heads <= 65535 && batch <= 65535, "attention: grid too large");
+  AttnParams p;
+  p.q = (const u16*)q; p.k = (const u16*)k; p.v = (const u16*)v; p.o = (u16*)o;
+  p.sq = sq; p.sk = sk; p.sv = sv; p.so = so; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.nq = nq; p.nkv = nkv; p.scale_log2 = scale * 1.44269504088896340736f;
+  dim3 grid((nq + 127) / 128, heads, batch), block(256);
+  hipLaunchKernelGGL(attn64_kernel, grid, block, 0, (hipStream_t)stream, p);
+  return sdmi_check_launch("attention");
+}

@@ -1,0 +1,224 @@
+// elementwise.hip - boundary layout transforms, weight pre-pack, the tiny-Cin first convolution, the skinny
+// (M <= 64) linear of the timestep-embedding path, the sinusoidal embedding, and the fused CFG + DDIM update.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ layout
+// NCHW fp32 <-> NHWC bf16 through a 32(pixels) x 32(channels) LDS tile (+1 pad), both sides coalesced.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, u16* __restrict__ dst, int c, int hw, int ldd) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int ch = c0 + i, px = p0 + tx;
+    tile[i][tx] = (ch < c && px < hw) ? src[((long long)n * c + ch) * hw + px] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int px = p0 + i, ch = c0 + tx;
+    if (px < hw && ch < c) dst[((long long)n * hw + px) * ldd + ch] = f2bf(tile[tx][i]);
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const u16* __restrict__ src, float* __restrict__ dst, int c, int hw, int lds) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int px = p0 + i, ch = c0 + tx;
+    tile[i][tx] = (px < hw && ch < c) ? bf2f(src[((long long)n * hw + px) * lds + ch]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int ch = c0 + i, px = p0 + tx;
+    if (ch < c && px < hw) dst[((long long)n * c + ch) * hw + px] = tile[tx][i];
+  }
+}
+extern "C" int sdmi_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int hw, int ldd, void* stream) {
+  SDMI_REQUIRE(src && dst && n > 0 && c > 0 && hw > 0 && ldd >= c && n <= 65535, "nchw_to_nhwc: bad argument");
+  dim3 grid((hw + 31) / 32, (c + 31) / 32, n);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, c, hw, ldd);
+  return sdmi_check_launch("nchw_to_nhwc");
+}
+extern "C" int sdmi_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int hw, int lds, void* stream) {
+  SDMI_REQUIRE(src && dst && n > 0 && c > 0 && hw > 0 && lds >= c && n <= 65535, "nhwc_to_nchw: bad argument");
+  dim3 grid((hw + 31) / 32, (c + 31) / 32, n);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)src, dst, c, hw, lds);
+  return sdmi_check_launch("nhwc_to_nchw");
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const float* __restrict__ src, u16* __restrict__ dst, int cols, int ld, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / cols;
+    const int cidx = (int)(i - r * cols);
+    dst[r * ld + cidx] = f2bf(src[i]);
+  }
+}
+extern "C" int sdmi_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int ld, void* stream) {
+  SDMI_REQUIRE(src && dst && rows > 0 && cols > 0 && ld >= cols, "f32_to_bf16_rows: bad argument");
+  const long long total = (long long)rows * cols;
+  long long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, cols, ld, total);
+  return sdmi_check_launch("f32_to_bf16_rows");
+}
+
+// ------------------------------------------------------------------------------------ weight pre-pack
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, u16* __restrict__ o, int cin, long long total) {
+  // o[co][tap][ci] = w[co][ci][tap]
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ci = (int)(i % cin);
+    const long long r = i / cin;
+    const int tap = (int)(r % 9);
+    const long long co = r / 9;
+    o[i] = f2bf(w[(co * cin + ci) * 9 + tap]);
+  }
+}
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, u16* __restrict__ o, int n, int k, int geglu, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / k;
+    const int kk = (int)(i - row * k);
+    long long srow = row;
+    if (geglu) {  // packed row 32*b + 16*s + j  <-  s ? gate row n/2 + 16*b + j : value row 16*b + j
+      const long long b = row >> 5;
+      const int s = (int)((row >> 4) & 1), j = (int)(row & 15);
+      srow = (s ? (long long)(n >> 1) : 0) + 16 * b + j;
+    }
+    o[i] = f2bf(w[srow * k + kk]);
+  }
+}
+extern "C" int sdmi_pack_conv3x3(const float* w_oihw, void* w_packed, int cout, int cin, void* stream) {
+  SDMI_REQUIRE(w_oihw && w_packed && cout > 0 && cin > 0, "pack_conv3x3: bad argument");
+  const long long total = (long long)cout * 9 * cin;
+  long long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_oihw, (u16*)w_packed, cin, total);
+  return sdmi_check_launch("pack_conv3x3");
+}
+extern "C" int sdmi_pack_linear(const float* w, void* w_packed, int n, int k, int geglu, void* stream) {
+  SDMI_REQUIRE(w && w_packed && n > 0 && k > 0, "pack_linear: bad argument");
+  SDMI_REQUIRE(!geglu || n % 32 == 0, "pack_linear: geglu needs n%%32==0 (n=%d)", n);
+  const long long total = (long long)n * k;
+  long long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, (u16*)w_packed, n, k, geglu, total);
+  return sdmi_check_launch("pack_linear");
+}
+
+// ------------------------------------------------------------------------------------ first conv (tiny Cin)
+// x NCHW fp32 (the caller's tensor), w OIHW fp32, out NHWC bf16.  thread = (pixel, 8 output channels); the
+// 9*CIN input taps sit in registers, weights are read through the scalar/L1 path (uniform per half-wave).
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, u16* __restrict__ out, int h,
+                                                         int wd, int cout, int ldc) {
+  const int n = blockIdx.z;
+  const int hw = h * wd;
+  const int pix = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int cg = blockIdx.y * 8 + (threadIdx.x >> 5);  // group of 8 output channels
+  if (pix >= hw || cg * 8 >= cout) return;
+  const int oy = pix / wd, ox = pix - oy * wd;
+  float in[CIN * 9];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+      in[ci * 9 + tap] = (iy >= 0 && iy < h && ix >= 0 && ix < wd) ? x[((long long)n * CIN + ci) * hw + iy * wd + ix] : 0.f;
+    }
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int co = cg * 8 + e;
+    float acc = 0.f;
+    if (co < cout) {
+      acc = bias[co];
+      const float* wp = w + (long long)co * CIN * 9;
+#pragma unroll
+      for (int i = 0; i < CIN * 9; ++i) acc += in[i] * wp[i];
+    }
+    o[e] = acc;
+  }
+  u16* op = out + ((long long)n * hw + pix) * ldc + cg * 8;
+  if (cg * 8 + 7 < cout) *(uint4*)op = pack8(o);
+  else for (int e = 0; e < 8; ++e) if (cg * 8 + e < cout) op[e] = f2bf(o[e]);
+}
+extern "C" int sdmi_conv3x3_in(const float* x_nchw, int n, int cin, int h, int w, const float* w_oihw, const float* bias,
+                               int cout, void* out, int ldc, void* stream) {
+  SDMI_REQUIRE(x_nchw && w_oihw && bias && out, "conv3x3_in: null pointer");
+  SDMI_REQUIRE(n > 0 && h > 0 && w > 0 && cout > 0 && n <= 65535, "conv3x3_in: bad shape");
+  SDMI_REQUIRE(ldc % 8 == 0 && ldc >= cout && ((uintptr_t)out & 15) == 0, "conv3x3_in: ldc/alignment");
+  dim3 grid((h * w + 31) / 32, ((cout + 7) / 8 + 7) / 8, n), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (cin) {
+    case 3: hipLaunchKernelGGL(conv3x3_in_kernel<3>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc); break;
+    case 4: hipLaunchKernelGGL(conv3x3_in_kernel<4>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc); break;
+    case 9: hipLaunchKernelGGL(conv3x3_in_kernel<9>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc); break;
+    default: sdmi_set_error("conv3x3_in: cin=%d unsupported (3, 4, 9)", cin); return SDMI_EINVAL;
+  }
+  return sdmi_check_launch("conv3x3_in");
+}
+
+// ------------------------------------------------------------------------------------ skinny linear
+// out[m][n] = bias[n] + sum_k f(x[m][k]) w[n][k]; one wave per output column n, lanes split K (16-byte
+// weight loads, weights streamed exactly once), rows handled 8 at a time.
+__global__ __launch_bounds__(256) void linear_small_m_kernel(const float* __restrict__ x, const u16* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int m,
+                                                             int n, int k, int silu) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= n) return;
+  const u16* wr = w + (long long)col * k;
+  for (int m0 = 0; m0 < m; m0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int kk = lane * 8; kk < k; kk += 512) {
+      float wf[8];
+      unpack8(*(const uint4*)(wr + kk), wf);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (m0 + r < m) {
+          const float4 a = *(const float4*)(x + (long long)(m0 + r) * k + kk);
+          const float4 b = *(const float4*)(x + (long long)(m0 + r) * k + kk + 4);
+          float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = silu ? silu_f(xv[e]) : xv[e];
+            acc[r] += v * wf[e];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float s = wave_sum(acc[r]);
+      if (lane == 0 && m0 + r < m) out[(long long)(m0 + r) * n + col] = s + (bias ? bias[col] : 0.f);
+    }
+  }
+}
+extern "C" int sdmi_linear_small_m(const float* x, const void* w, const float* bias, float* out, int m, int n, int k,
+                                   uint32_t flags, void* stream) {
+  SDMI_REQUIRE(x && w && out && m > 0 && n > 0 && k > 0, "linear_small_m: bad argument");
+  SDMI_REQUIRE(m <= 64, "linear_small_m: m=%d > 64 (use sdmi_gemm)", m);
+  SDMI_REQUIRE(k % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "linear_small_m: k%%8 / alignment");
+  hipLaunchKernelGGL(linear_small_m_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (const u16*)w, bias, out,
+                     m, n, k, (flags & SDMI_F_SILU) ? 1 : 0);
+  return sdmi_check_launch("linear_small_m");
+}
+
+// ------------------------------------------------------------------------------------ timestep embedding
+__global__ void timestep_embedding_kernel(const long long* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out,
+                                          int m, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * half) return;
+  const int r = i / half, j = i - r * half;
+  const float a = (float)t[r] * freqs[j];
+  out[(long long)r * 2 * half + j] = cosf(a);
+  out[(long long)r * 2 * half + half + j] = sinf(a);
+}
+extern "C" int sdmi_timestep_embedding(const int64_t* t, const float* freqs, float* out, int m, int half, void* stream) {
+  SDMI_REQUIRE(t && freqs && out && m > 0 && half > 0, "timestep_embedding: bad argument");
+  const int total = m * half;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)t,
+                     freqs, out, m, half);
+  return sdmi_check_launch("timestep_embedding");
+}

@@ -1,0 +1,286 @@
+// igemm.hip - bf16 MFMA GEMM  out[M][N] = A[M][K] * W[N][K]^T  with an optional on-the-fly im2col
+// A-loader (3x3 convolution, stride 1/2, explicit padding, nearest-2x upsample gather) and a fused
+// epilogue (alpha, bias, per-sample channel bias = timestep embedding, residual, GEGLU, NCHW-fp32 out).
+//
+// Replaces nn.Conv2d(k=3) / nn.Linear / nn.Conv2d(k=1) / F.interpolate / F.pad / GEGLU of the reference
+// (layers/ResBlock.py:17-19,:36-37,:67-76; layers/SpatialTransformer.py:22-26,:62-66,:110-129,:199,:204).
+//
+// Structure (gfx950): 256 threads = 4 waves in a 2x2 grid over a BM x BN tile, BK = 64.  Both operands
+// are K-contiguous, staged global -> registers -> LDS (16 B per lane, XOR-swizzled 128-B rows so the
+// ds_read_b128 fragment reads are bank-conflict free), double-buffered: the global loads of tile k+1 are
+// issued before the MFMAs of tile k and written to the other LDS buffer after them (one barrier per
+// K-tile).  v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand, so a lane ends up with 4
+// consecutive output channels of one pixel (8-byte bf16 stores, 16-byte fp32 bias loads).
+#include "common.h"
+
+struct IgemmParams {
+  const u16* a; const u16* w; void* out; const float* bias; const float* rowbias; const u16* res;
+  long long sa, sw, sc;
+  int lda, ldw, ldc, ldr, ldrb;
+  int M, N, K;
+  int rows_per_sample;
+  float alpha;
+  uint32_t flags;
+  // conv geometry (CONV only)
+  int H, W, Cin, Ho, Wo, stride, pad_t, pad_l, ups, kt_per_tap;
+  int nk;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int MT = BM / 32, NT = BN / 32, PA = BM / 32, PB = BN / 32;
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * (BM + BN) * 64];
+  u16* sA = smem;
+  u16* sB = smem + 2 * BM * 64;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1, l15 = lane & 15, lq = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int brow = (bid / tiles_n) * BM, bcol = (bid % tiles_n) * BN;
+  const int bz = blockIdx.y;
+  const u16* A = p.a + (long long)bz * p.sa;
+  const u16* Wp = p.w + (long long)bz * p.sw;
+  const int chunk = t & 7, r0 = t >> 3;
+
+  // ---- per-thread row bookkeeping (fixed over the K loop) ----
+  bool a_ok[PA];
+  const u16* a_ptr[PA];
+  int a_oy[PA], a_ox[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int gm = brow + r0 + 32 * i;
+    a_ok[i] = gm < p.M;
+    const int gmc = a_ok[i] ? gm : 0;
+    if constexpr (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int img = gmc / hw, rem = gmc - img * hw;
+      a_oy[i] = rem / p.Wo;
+      a_ox[i] = rem - a_oy[i] * p.Wo;
+      a_ptr[i] = A + (long long)img * p.H * p.W * p.lda;
+    } else {
+      a_oy[i] = a_ox[i] = 0;
+      a_ptr[i] = A + (long long)gmc * p.lda + chunk * 8;
+    }
+  }
+  bool b_ok[PB];
+  const u16* b_ptr[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int gn = bcol + r0 + 32 * i;
+    b_ok[i] = gn < p.N;
+    b_ptr[i] = Wp + (long long)(b_ok[i] ? gn : 0) * p.ldw + chunk * 8;
+  }
+
+  uint4 ra[PA], rb[PB];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  int tap = 0, cb = 0;  // CONV: position of the NEXT tile to load
+
+  auto load_tile = [&](int kt) {
+    if constexpr (CONV) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int c = cb * 64 + chunk * 8;
+      const bool cok = c < p.Cin;
+      const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        int iy = a_oy[i] * p.stride + ky - p.pad_t, ix = a_ox[i] * p.stride + kx - p.pad_l;
+        const bool ok = a_ok[i] && cok && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
+        iy >>= p.ups;
+        ix >>= p.ups;
+        ra[i] = ok ? *(const uint4*)(a_ptr[i] + ((long long)(iy * p.W + ix) * p.lda + c)) : zero4;
+      }
+      const int wk = tap * p.Cin + c - chunk * 8;  // b_ptr already carries chunk*8
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = (b_ok[i] && cok) ? *(const uint4*)(b_ptr[i] + wk) : zero4;
+      if (++cb == p.kt_per_tap) { cb = 0; ++tap; }
+    } else {
+      const bool kok = kt * 64 + chunk * 8 < p.K;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = (a_ok[i] && kok) ? *(const uint4*)(a_ptr[i] + kt * 64) : zero4;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = (b_ok[i] && kok) ? *(const uint4*)(b_ptr[i] + kt * 64) : zero4;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *(uint4*)&sA[buf * BM * 64 + lds_off(r0 + 32 * i, chunk)] = ra[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *(uint4*)&sB[buf * BN * 64 + lds_off(r0 + 32 * i, chunk)] = rb[i];
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const bool more = kt + 1 < p.nk;
+    if (more) load_tile(kt + 1);
+    const u16* cA = sA + cur * BM * 64;
+    const u16* cB = sB + cur * BN * 64;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = lq + 4 * kk;
+      bf16x8 af[MT], wf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)&cA[lds_off(wr * (BM / 2) + i * 16 + l15, ch)];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)&cB[lds_off(wc * (BN / 2) + j * 16 + l15, ch)];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds out[m][n0..n0+3], m = tile row l15, n0 = 4*lq within each 16x16 tile ----
+  const uint32_t fl = p.flags;
+  const int hwo = p.rows_per_sample;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = brow + wr * (BM / 2) + i * 16 + l15;
+    if (m >= p.M) continue;
+    int sample = 0, pix = m;
+    if (fl & (SDMI_F_ROWBIAS | SDMI_F_OUT_NCHW_F32)) { sample = m / hwo; pix = m - sample * hwo; }
+    if (fl & SDMI_F_GEGLU) {
+      const int half = p.N >> 1;
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int nb0 = bcol + wc * (BN / 2) + j * 16;
+        if (nb0 >= p.N) continue;
+        const int oc = (nb0 >> 5) * 16 + lq * 4;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xv = acc[i][j][e] * p.alpha, gv = acc[i][j + 1][e] * p.alpha;
+          if (fl & SDMI_F_BIAS) { xv += p.bias[oc + e]; gv += p.bias[half + oc + e]; }
+          y[e] = xv * gelu_erf(gv);
+        }
+        u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + oc;
+        *(uint2*)o = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n0 = bcol + wc * (BN / 2) + j * 16 + lq * 4;
+      if (n0 >= p.N) continue;
+      const bool full = n0 + 3 < p.N;
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = acc[i][j][e] * p.alpha;
+        const int n = (full || n0 + e < p.N) ? n0 + e : n0;
+        if (fl & SDMI_F_BIAS) y[e] += p.bias[n];
+        if (fl & SDMI_F_ROWBIAS) y[e] += p.rowbias[(long long)sample * p.ldrb + n];
+      }
+      if (fl & SDMI_F_RESIDUAL) {
+        const u16* r = p.res + (long long)bz * p.sc + (long long)m * p.ldr + n0;
+        if (full) {
+          const uint2 rv = *(const uint2*)r;
+          y[0] += __uint_as_float(rv.x << 16); y[1] += __uint_as_float(rv.x & 0xffff0000u);
+          y[2] += __uint_as_float(rv.y << 16); y[3] += __uint_as_float(rv.y & 0xffff0000u);
+        } else {
+          for (int e = 0; e < 4; ++e) if (n0 + e < p.N) y[e] += bf2f(r[e]);
+        }
+      }
+      if (fl & SDMI_F_OUT_NCHW_F32) {
+        float* o = (float*)p.out + ((long long)sample * p.N + n0) * hwo + pix;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (full || n0 + e < p.N) o[(long long)e * hwo] = y[e];
+      } else if (fl & SDMI_F_OUT_F32) {
+        float* o = (float*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + n0;
+        if (full) *(float4*)o = make_float4(y[0], y[1], y[2], y[3]);
+        else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = y[e];
+      } else {
+        u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + n0;
+        if (full) *(uint2*)o = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+        else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = f2bf(y[e]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+template <bool CONV>
+static int launch_igemm(const IgemmParams& p, int batch, hipStream_t st) {
+  // tile choice: wide N tile unless N is small or would waste > ~1/6 of it; halve BM when the grid
+  // would not cover the 256 CUs.
+  const bool bn128 = (p.N % 128 == 0) || (p.N > 512);
+  const int bn = bn128 ? 128 : 64;
+  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * batch;
+  const bool bm128 = p.M > 64 && tiles128 >= 256;
+  const int bm = bm128 ? 128 : 64;
+  const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+  dim3 grid(nb, batch), block(256);
+  if (bm128 && bn128) hipLaunchKernelGGL((igemm_kernel<128, 128, CONV>), grid, block, 0, st, p);
+  else if (bm128) hipLaunchKernelGGL((igemm_kernel<128, 64, CONV>), grid, block, 0, st, p);
+  else if (bn128) hipLaunchKernelGGL((igemm_kernel<64, 128, CONV>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((igemm_kernel<64, 64, CONV>), grid, block, 0, st, p);
+  return sdmi_check_launch(CONV ? "conv3x3" : "gemm");
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
+                         int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
+                         int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* stream) {
+  SDMI_REQUIRE(a && w && out, "gemm: null pointer");
+  SDMI_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0, "gemm: bad shape m=%d n=%d k=%d batch=%d", m, n, k, batch);
+  SDMI_REQUIRE(k % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k, "gemm: k/lda/ldw must be multiples of 8 (k=%d lda=%d ldw=%d)", k, lda, ldw);
+  SDMI_REQUIRE(aligned16(a) && aligned16(w) && aligned16(out), "gemm: pointers must be 16-byte aligned");
+  SDMI_REQUIRE(sa % 8 == 0 && sw % 8 == 0 && sc % 4 == 0, "gemm: batch strides must keep 16-byte alignment");
+  SDMI_REQUIRE(!(flags & SDMI_F_BIAS) || bias, "gemm: SDMI_F_BIAS without bias");
+  SDMI_REQUIRE(!(flags & SDMI_F_ROWBIAS) || (rowbias && rows_per_sample > 0), "gemm: SDMI_F_ROWBIAS without rowbias/rows_per_sample");
+  SDMI_REQUIRE(!(flags & SDMI_F_RESIDUAL) || (residual && ldr % 4 == 0 && ((uintptr_t)residual & 7) == 0), "gemm: bad residual");
+  SDMI_REQUIRE(!(flags & SDMI_F_OUT_NCHW_F32) || (rows_per_sample > 0 && batch == 1), "gemm: NCHW output needs rows_per_sample, batch 1");
+  if (flags & SDMI_F_GEGLU) {
+    SDMI_REQUIRE(n % 32 == 0 && !(flags & (SDMI_F_RESIDUAL | SDMI_F_ROWBIAS | SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_F32)), "gemm: GEGLU needs n%%32==0 and no other epilogue");
+    SDMI_REQUIRE(ldc % 4 == 0 && ldc >= n / 2, "gemm: GEGLU ldc");
+  } else if (!(flags & SDMI_F_OUT_NCHW_F32)) {
+    SDMI_REQUIRE(ldc % 4 == 0 && ldc >= n, "gemm: ldc must be a multiple of 4 and >= n (ldc=%d n=%d)", ldc, n);
+  }
+  IgemmParams p = {};
+  p.a = (const u16*)a; p.w = (const u16*)w; p.out = out; p.bias = bias; p.rowbias = rowbias; p.res = (const u16*)residual;
+  p.sa = sa; p.sw = sw; p.sc = sc; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
+  p.M = m; p.N = n; p.K = k; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.alpha = alpha; p.flags = flags;
+  p.nk = (k + 63) / 64;
+  return launch_igemm<false>(p, batch, (hipStream_t)stream);
+}
+
+extern "C" int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout, int hout,
+                            int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias, int ldrb,
+                            const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* stream) {
+  SDMI_REQUIRE(x && w_packed && out, "conv3x3: null pointer");
+  SDMI_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && hout > 0 && wout > 0, "conv3x3: bad shape");
+  SDMI_REQUIRE(cin % 8 == 0 && ldx % 8 == 0 && ldx >= cin, "conv3x3: cin and ldx must be multiples of 8 (cin=%d ldx=%d)", cin, ldx);
+  SDMI_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride %d", stride);
+  SDMI_REQUIRE(aligned16(x) && aligned16(w_packed) && aligned16(out), "conv3x3: pointers must be 16-byte aligned");
+  const int ups = (flags & SDMI_F_UPSAMPLE2X) ? 1 : 0;
+  // every tap of every output pixel must fall inside the zero-padded (upsampled) input by at most the pad
+  SDMI_REQUIRE((hout - 1) * stride + 2 - pad_t <= (h << ups) && (wout - 1) * stride + 2 - pad_l <= (w << ups) && pad_t >= 0 && pad_l >= 0 && pad_t <= 1 && pad_l <= 1,
+               "conv3x3: geometry out of range (h=%d w=%d hout=%d wout=%d stride=%d pad=%d,%d ups=%d)", h, w, hout, wout, stride, pad_t, pad_l, ups);
+  SDMI_REQUIRE(!(flags & SDMI_F_BIAS) || bias, "conv3x3: SDMI_F_BIAS without bias");
+  SDMI_REQUIRE(!(flags & SDMI_F_ROWBIAS) || rowbias, "conv3x3: SDMI_F_ROWBIAS without rowbias");
+  SDMI_REQUIRE(!(flags & SDMI_F_RESIDUAL) || (residual && ldr % 4 == 0 && ((uintptr_t)residual & 7) == 0), "conv3x3: bad residual");
+  SDMI_REQUIRE(!(flags & (SDMI_F_GEGLU | SDMI_F_OUT_F32)), "conv3x3: unsupported flag");
+  if (!(flags & SDMI_F_OUT_NCHW_F32)) SDMI_REQUIRE(ldc % 4 == 0 && ldc >= cout, "conv3x3: ldc");
+  IgemmParams p = {};
+  p.a = (const u16*)x; p.w = (const u16*)w_packed; p.out = out; p.bias = bias; p.rowbias = rowbias; p.res = (const u16*)residual;
+  p.lda = ldx; p.ldw = 9 * cin; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
+  p.M = n * hout * wout; p.N = cout; p.K = 9 * cin; p.rows_per_sample = hout * wout; p.alpha = 1.0f; p.flags = flags;
+  p.H = h; p.W = w; p.Cin = cin; p.Ho = hout; p.Wo = wout; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.ups = ups;
+  p.kt_per_tap = (cin + 63) / 64;
+  p.nk = 9 * p.kt_per_tap;
+  return launch_igemm<true>(p, 1, (hipStream_t)stream);
+}

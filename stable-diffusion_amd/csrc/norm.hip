@@ -1,0 +1,303 @@
+// norm.hip - HBM-bound normalisation kernels on NHWC bf16 activations (16-byte vector loads/stores).
+//   GroupNorm(32)(+SiLU)  nn.GroupNorm + nn.SiLU  (layers/ResBlock.py:65-66,:72-73; Unet.py:104-106;
+//                         AutoencoderKL.py:193-194; layers/SpatialTransformer.py:134,:212)
+//   LayerNorm             nn.LayerNorm            (layers/SpatialTransformer.py:177-184)
+//   row softmax           the softmax inside the VAE's single-head attention (:151)
+// All reductions run in a fixed order (no float atomics): results are bit-reproducible run to run and
+// GPU to GPU, which the image-sharded multi-GPU path relies on.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ GroupNorm
+// pass 1a: per-block partial (sum, sumsq) of every group.  grid (nblk, N); a wave reads whole rows
+// (lane -> 8-channel chunk lane, lane+64, ...), keeps per-channel sums in registers, the 4 waves
+// combine through LDS in wave order, then thread g folds the channels of group g.
+template <int NS>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const u16* __restrict__ x, int hw, int c, int ldx,
+                                                         int rows_per_block, int cpg, float* __restrict__ partial) {
+  __shared__ float s_sum[2560], s_sq[2560];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
+  const int cc = c >> 3;
+  const int row_beg = blk * rows_per_block;
+  const int row_end = min(hw, row_beg + rows_per_block);
+  float a[NS][8], b[NS][8];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[s][e] = b[s][e] = 0.f;
+  const u16* base = x + (long long)n * hw * ldx;
+  for (int row = row_beg + wv; row < row_end; row += 4) {
+    const u16* rp = base + (long long)row * ldx;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int ch = lane + 64 * s;
+      if (ch < cc) {
+        float f[8];
+        unpack8(*(const uint4*)(rp + ch * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[s][e] += f[e]; b[s][e] += f[e] * f[e]; }
+      }
+    }
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int ch = lane + 64 * s;
+        if (ch < cc) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ci = ch * 8 + e;
+            if (w == 0) { s_sum[ci] = a[s][e]; s_sq[ci] = b[s][e]; }
+            else { s_sum[ci] += a[s][e]; s_sq[ci] += b[s][e]; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int groups = c / cpg;
+  if (t < groups) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < cpg; ++i) { s0 += s_sum[t * cpg + i]; s1 += s_sq[t * cpg + i]; }
+    float* o = partial + (((long long)n * nblk + blk) * groups + t) * 2;
+    o[0] = s0;
+    o[1] = s1;
+  }
+}
+
+// pass 1b: fold the partials (fp64), emit per-(sample,channel) scale/shift.  grid N, 256 threads.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int groups, int c,
+                                                          int hw, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale_shift) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int t = threadIdx.x, n = blockIdx.x;
+  const int g = t >> 3, sub = t & 7;  // 8 threads per group, 32 groups per pass
+  for (int g0 = 0; g0 < groups; g0 += 32) {
+    const int gg = g0 + g;
+    double s0 = 0.0, s1 = 0.0;
+    if (gg < groups)
+      for (int b = sub; b < nblk; b += 8) {
+        const float* pp = partial + (((long long)n * nblk + b) * groups + gg) * 2;
+        s0 += (double)pp[0];
+        s1 += (double)pp[1];
+      }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if (sub == 0 && gg < groups) {
+      const double cnt = (double)hw * (double)(c / groups);
+      const double mean = s0 / cnt;
+      double var = s1 / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[gg & 63] = (float)mean;
+      s_rstd[gg & 63] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  const int cpg = c / groups;
+  for (int ci = t; ci < c; ci += 256) {
+    const int gg = ci / cpg;
+    const float sc = gamma[ci] * s_rstd[gg & 63];
+    float2 o;
+    o.x = sc;
+    o.y = beta[ci] - s_mean[gg & 63] * sc;
+    *(float2*)(scale_shift + ((long long)n * c + ci) * 2) = o;
+  }
+}
+
+// pass 2: y = act(x*scale + shift).  one thread per 8-channel chunk, grid-stride.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x, int ldx, const float* __restrict__ ss,
+                                                       u16* __restrict__ y, int ldy, int hw, int c, long long total,
+                                                       int silu) {
+  const int cc = c >> 3;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long row = idx / cc;
+    const int ch = (int)(idx - row * cc);
+    const int n = (int)(row / hw);
+    float f[8];
+    unpack8(*(const uint4*)(x + row * ldx + ch * 8), f);
+    const float4* sp = (const float4*)(ss + ((long long)n * c + ch * 8) * 2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 v = sp[e];
+      float a0 = f[2 * e] * v.x + v.y, a1 = f[2 * e + 1] * v.z + v.w;
+      if (silu) { a0 = silu_f(a0); a1 = silu_f(a1); }
+      f[2 * e] = a0;
+      f[2 * e + 1] = a1;
+    }
+    *(uint4*)(y + row * ldy + ch * 8) = pack8(f);
+  }
+}
+
+static int gn_nblk(int hw) {
+  int nb = (hw + 63) / 64;
+  return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+}
+
+extern "C" int64_t sdmi_groupnorm_ws_bytes(int n, int hw, int c) {
+  (void)c;
+  return (int64_t)n * gn_nblk(hw) * 64 * 2 * sizeof(float);
+}
+
+extern "C" int sdmi_groupnorm_stats(const void* x, int n, int hw, int c, int ldx, int groups, const float* gamma,
+                                    const float* beta, float eps, float* scale_shift, void* ws, void* stream) {
+  SDMI_REQUIRE(x && gamma && beta && scale_shift && ws, "groupnorm_stats: null pointer");
+  SDMI_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldx >= c, "groupnorm_stats: c and ldx must be multiples of 8 (c=%d ldx=%d)", c, ldx);
+  SDMI_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "groupnorm_stats: groups=%d does not divide c=%d", groups, c);
+  SDMI_REQUIRE(c <= 2560, "groupnorm_stats: c=%d > 2560", c);
+  SDMI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)scale_shift & 15) == 0, "groupnorm_stats: alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = gn_nblk(hw);
+  const int rpb = (hw + nblk - 1) / nblk;
+  const int ns = (c / 8 + 63) / 64;
+  dim3 grid(nblk, n), block(256);
+  const u16* xp = (const u16*)x;
+  float* part = (float*)ws;
+  switch (ns) {
+    case 1: hipLaunchKernelGGL(gn_partial_kernel<1>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
+    case 2: hipLaunchKernelGGL(gn_partial_kernel<2>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
+    case 3: hipLaunchKernelGGL(gn_partial_kernel<3>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
+    case 4: hipLaunchKernelGGL(gn_partial_kernel<4>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
+    default: hipLaunchKernelGGL(gn_partial_kernel<5>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
+  }
+  int rc = sdmi_check_launch("groupnorm partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), block, 0, st, part, nblk, groups, c, hw, gamma, beta, eps, scale_shift);
+  return sdmi_check_launch("groupnorm finalize");
+}
+
+extern "C" int sdmi_groupnorm_apply(const void* x, int ldx, const float* scale_shift, void* y, int ldy, int n, int hw,
+                                    int c, uint32_t flags, void* stream) {
+  SDMI_REQUIRE(x && scale_shift && y, "groupnorm_apply: null pointer");
+  SDMI_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c, "groupnorm_apply: c/ldx/ldy must be multiples of 8");
+  SDMI_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)scale_shift) & 15) == 0, "groupnorm_apply: alignment");
+  const long long total = (long long)n * hw * (c / 8);
+  long long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const u16*)x, ldx, scale_shift,
+                     (u16*)y, ldy, hw, c, total, (flags & SDMI_F_SILU) ? 1 : 0);
+  return sdmi_check_launch("groupnorm apply");
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm
+// one wave per row, the row lives in registers (two-pass mean / variance like torch).
+template <int NS>
+__global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, u16* __restrict__ y,
+                                                        int ldy, int rows, int c) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int cc = c >> 3;
+  float f[NS][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int ch = lane + 64 * s;
+    if (ch < cc) {
+      unpack8(*(const uint4*)(x + (long long)row * ldx + ch * 8), f[s]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += f[s][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[s][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)c;
+  float sq = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (lane + 64 * s < cc) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[s][e] - mean; sq += d * d; }
+    }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)c + eps);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int ch = lane + 64 * s;
+    if (ch < cc) {
+      const float4* gp = (const float4*)(gamma + ch * 8);
+      const float4* bp = (const float4*)(beta + ch * 8);
+      const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+      float o[8];
+      o[0] = (f[s][0] - mean) * rstd * g0.x + b0.x; o[1] = (f[s][1] - mean) * rstd * g0.y + b0.y;
+      o[2] = (f[s][2] - mean) * rstd * g0.z + b0.z; o[3] = (f[s][3] - mean) * rstd * g0.w + b0.w;
+      o[4] = (f[s][4] - mean) * rstd * g1.x + b1.x; o[5] = (f[s][5] - mean) * rstd * g1.y + b1.y;
+      o[6] = (f[s][6] - mean) * rstd * g1.z + b1.z; o[7] = (f[s][7] - mean) * rstd * g1.w + b1.w;
+      *(uint4*)(y + (long long)row * ldy + ch * 8) = pack8(o);
+    }
+  }
+}
+
+extern "C" int sdmi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
+                              int rows, int c, void* stream) {
+  SDMI_REQUIRE(x && gamma && beta && y, "layernorm: null pointer");
+  SDMI_REQUIRE(rows > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c, "layernorm: c/ldx/ldy must be multiples of 8");
+  SDMI_REQUIRE(c <= 2560, "layernorm: c=%d > 2560", c);
+  SDMI_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm: alignment");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4), block(256);
+  const int ns = (c / 8 + 63) / 64;
+  const u16* xp = (const u16*)x;
+  u16* yp = (u16*)y;
+  switch (ns) {
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, xp, ldx, gamma, beta, eps, yp, ldy, rows, c); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, xp, ldx, gamma, beta, eps, yp, ldy, rows, c); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, xp, ldx, gamma, beta, eps, yp, ldy, rows, c); break;
+    case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, xp, ldx, gamma, beta, eps, yp, ldy, rows, c); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, st, xp, ldx, gamma, beta, eps, yp, ldy, rows, c); break;
+  }
+  return sdmi_check_launch("layernorm");
+}
+
+// ------------------------------------------------------------------------------------ row softmax
+// block per row: y = softmax(x*scale) , fp32 in (L2-resident re-reads), bf16 out.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, u16* __restrict__ y, int ldy,
+                                                           int cols, float scale_log2) {
+  __shared__ float red[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const float* xr = x + (long long)blockIdx.x * ldx;
+  u16* yr = y + (long long)blockIdx.x * ldy;
+  const int c4 = cols >> 2;
+  float mx = -1e30f;
+  for (int i = t; i < c4; i += 256) {
+    const float4 v = ((const float4*)xr)[i];
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  for (int i = c4 * 4 + t; i < cols; i += 256) mx = fmaxf(mx, xr[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2;
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = t; i < c4; i += 256) {
+    const float4 v = ((const float4*)xr)[i];
+    sum += __builtin_amdgcn_exp2f(v.x * scale_log2 - mx) + __builtin_amdgcn_exp2f(v.y * scale_log2 - mx) +
+           __builtin_amdgcn_exp2f(v.z * scale_log2 - mx) + __builtin_amdgcn_exp2f(v.w * scale_log2 - mx);
+  }
+  for (int i = c4 * 4 + t; i < cols; i += 256) sum += __builtin_amdgcn_exp2f(xr[i] * scale_log2 - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wv] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = t; i < c4; i += 256) {
+    const float4 v = ((const float4*)xr)[i];
+    const uint2 o = make_uint2(pack2bf(__builtin_amdgcn_exp2f(v.x * scale_log2 - mx) * inv, __builtin_amdgcn_exp2f(v.y * scale_log2 - mx) * inv),
+                               pack2bf(__builtin_amdgcn_exp2f(v.z * scale_log2 - mx) * inv, __builtin_amdgcn_exp2f(v.w * scale_log2 - mx) * inv));
+    ((uint2*)yr)[i] = o;
+  }
+  for (int i = c4 * 4 + t; i < cols; i += 256) yr[i] = f2bf(__builtin_amdgcn_exp2f(xr[i] * scale_log2 - mx) * inv);
+}
+
+extern "C" int sdmi_softmax_rows(const float* x, int ldx, void* y, int ldy, int rows, int cols, float scale, void* stream) {
+  SDMI_REQUIRE(x && y && rows > 0 && cols > 0, "softmax_rows: bad argument");
+  SDMI_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= cols && ldy >= cols, "softmax_rows: ldx/ldy must be multiples of 4");
+  SDMI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, "softmax_rows: alignment");
+  // scale > 0 is assumed (max(x)*scale == max(x*scale))
+  SDMI_REQUIRE(scale > 0.f, "softmax_rows: scale must be positive");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, (u16*)y, ldy, cols,
+                     scale * 1.44269504088896340736f);
+  return sdmi_check_launch("softmax_rows");
+}

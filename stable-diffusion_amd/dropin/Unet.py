@@ -1,0 +1,158 @@
+"""Drop-in for the reference's Unet.py: `Unet()` with the same module tree / state_dict keys and
+`forward(x, timesteps=None, context=None)` on NCHW fp32 tensors, executed on libsdmi355.so.
+
+Differences in HOW (not WHAT): activations are NHWC bf16 views between blocks; the first conv reads the caller's
+NCHW fp32 input directly and the last conv writes NCHW fp32 directly; the 12 skip `torch.cat`s of Unet.py:132 are
+gone - every producer writes straight into its half of a pre-sized concat buffer; the time-embedding MLP and all 22
+`emb_proj` projections run as three skinny-GEMM launches whose result the conv epilogues add per sample."""
+import torch
+from torch import nn
+
+from layers.ResBlock import ResBlock, Downsample, Upsample
+from layers.SpatialTransformer import SpatialTransformer
+from stable_diffusion_amd import engine as E
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """Sinusoidal embedding [cos | sin] (reference Unet.py:7-25), computed on the device."""
+    return E.timestep_embedding(timesteps, dim, max_period)
+
+
+# SD-2 inpainting UNet hyper-parameters (reference Unet.py:30-37)
+IN_CH, MODEL_CH, OUT_CH = 9, 320, 4
+RES_BLOCKS, ATTN_DS, CH_MULT, HEAD_CH = (2, 2, 2, 2), (1, 2, 4), (1, 2, 4, 4), 64
+
+
+class Unet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.emb_channels = MODEL_CH
+        temb = MODEL_CH * 4
+        self.time_embed = nn.Sequential(nn.Linear(MODEL_CH, temb), nn.SiLU(), nn.Linear(temb, temb))
+
+        def stage(cin, cout, ds, up=False):
+            mods = [ResBlock(cin, cout, temb)]
+            if ds in ATTN_DS:
+                mods.append(SpatialTransformer(cout, cout // HEAD_CH))
+            if up:
+                mods.append(Upsample(cout, out_channels=cout))
+            return nn.ModuleList(mods)
+
+        self.input_blocks = nn.ModuleList([nn.Conv2d(IN_CH, MODEL_CH, 3, padding=1)])
+        skip_ch, ch, ds = [MODEL_CH], MODEL_CH, 1
+        for level, mult in enumerate(CH_MULT):
+            for _ in range(RES_BLOCKS[level]):
+                self.input_blocks.append(stage(ch, mult * MODEL_CH, ds))
+                ch = mult * MODEL_CH
+                skip_ch.append(ch)
+            if level != len(CH_MULT) - 1:
+                self.input_blocks.append(Downsample(ch, out_channels=ch))
+                skip_ch.append(ch)
+                ds *= 2
+        self.middle_block = nn.ModuleList([ResBlock(ch, ch, temb), SpatialTransformer(ch, ch // HEAD_CH), ResBlock(ch, ch, temb)])
+        self.output_blocks = nn.ModuleList([])
+        for level in reversed(range(len(CH_MULT))):
+            for i in range(RES_BLOCKS[level] + 1):
+                last = bool(level) and i == RES_BLOCKS[level]
+                self.output_blocks.append(stage(ch + skip_ch.pop(), CH_MULT[level] * MODEL_CH, ds, up=last))
+                ch = CH_MULT[level] * MODEL_CH
+                if last:
+                    ds //= 2
+        self.out = nn.Sequential(nn.GroupNorm(num_groups=32, num_channels=ch), nn.SiLU(), nn.Conv2d(MODEL_CH, OUT_CH, 3, padding=1))
+
+    # ------------------------------------------------------------------ helpers
+    def _resblocks(self):
+        for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
+            if isinstance(blk, nn.ModuleList):
+                for m in blk:
+                    if isinstance(m, ResBlock):
+                        yield m
+
+    def _embeddings(self, timesteps):
+        """t_emb MLP (Unet.py:112-114) + every ResBlock's emb_proj(SiLU(t_emb)) (layers/ResBlock.py:70), batched."""
+        t = E.timestep_embedding(timesteps, self.emb_channels)
+        l0, l2 = self.time_embed[0], self.time_embed[2]
+        h = E.linear_small_m(t, E.packed_linear((l0.weight,)), l0.bias)
+        t_emb = E.linear_small_m(h, E.packed_linear((l2.weight,)), l2.bias, silu_in=True)
+        rbs = list(self._resblocks())
+        w = E.packed_linear(tuple(rb.emb_proj.weight for rb in rbs))
+        b = E.stacked_f32(tuple(rb.emb_proj.bias for rb in rbs))
+        allp = E.linear_small_m(t_emb, w, b, silu_in=True)          # (Bc, sum C_out)
+        offs, o = {}, 0
+        for rb in rbs:
+            offs[id(rb)] = allp.data_ptr() + 4 * o
+            o += rb.emb_proj.weight.shape[0]
+        return allp, offs, allp.shape[1]
+
+    @staticmethod
+    def _run_stage(mods, h, emb, ldrb, ctx, out):
+        n = len(mods)
+        for i, m in enumerate(mods):
+            dst = out if i == n - 1 else None
+            if isinstance(m, ResBlock):
+                h = m.run(h, emb[id(m)], ldrb, out=dst)
+            elif isinstance(m, SpatialTransformer):
+                h = m.run(h, ctx, out=dst)
+            else:
+                h = m.run(h, out=dst)
+        return h
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None):
+        if isinstance(context, list):
+            context = context[0]
+        x = x.contiguous().float()
+        n, _, hh, ww = x.shape
+        dev = x.device
+        keep, emb, ldrb = self._embeddings(timesteps)
+        ctx = E.tokens_from_f32(context)
+
+        # ---- geometry + concat plan: skip k is consumed by output block (K-1-k) next to an `h` of cat_c1[k] channels
+        nin = len(self.input_blocks)
+        skip_c, skip_hw = [], []
+        ch_h, ch_w = hh, ww
+        for blk in self.input_blocks:
+            if isinstance(blk, nn.Conv2d):
+                c = blk.out_channels
+            elif isinstance(blk, Downsample):
+                c = blk.conv.out_channels
+                ch_h, ch_w = (ch_h + 2 - 3) // 2 + 1, (ch_w + 2 - 3) // 2 + 1
+            else:
+                c = blk[0].conv1.out_channels
+            skip_c.append(c)
+            skip_hw.append((ch_h, ch_w))
+        cat = [None] * nin
+        for j, blk in enumerate(self.output_blocks):
+            k = nin - 1 - j
+            c1 = blk[0].norm1.num_channels - skip_c[k]
+            sh, sw = skip_hw[k]
+            cat[k] = E.new_act(n, sh, sw, c1 + skip_c[k], dev)
+        c1_of = lambda k: cat[k].c - skip_c[k]
+
+        # ---- down path: block i writes its output into the upper half of cat[i]
+        h = None
+        for i, blk in enumerate(self.input_blocks):
+            dst = cat[i].cols(c1_of(i), skip_c[i])
+            if isinstance(blk, nn.Conv2d):
+                E.L.call("sdmi_conv3x3_in", x.data_ptr(), n, x.shape[1], hh, ww, blk.weight.data_ptr(), blk.bias.data_ptr(),
+                         blk.out_channels, dst.ptr, dst.ld, E._stream())
+                h = dst
+            elif isinstance(blk, Downsample):
+                h = blk.run(h, out=dst)
+            else:
+                h = self._run_stage(blk, h, emb, ldrb, ctx, dst)
+        # ---- middle: result goes into the lower half of the deepest concat buffer
+        h = self.middle_block[0].run(h, emb[id(self.middle_block[0])], ldrb)
+        h = self.middle_block[1].run(h, ctx)
+        h = self.middle_block[2].run(h, emb[id(self.middle_block[2])], ldrb, out=cat[nin - 1].cols(0, c1_of(nin - 1)))
+        # ---- up path
+        nout = len(self.output_blocks)
+        for j, blk in enumerate(self.output_blocks):
+            k = nin - 1 - j
+            dst = cat[k - 1].cols(0, c1_of(k - 1)) if j + 1 < nout else None
+            h = self._run_stage(blk, cat[k], emb, ldrb, ctx, dst)
+        gn, conv = self.out[0], self.out[2]
+        h = E.groupnorm(h, gn.weight, gn.bias, gn.eps, silu=True)
+        del keep
+        return E.conv3x3(h, conv.weight, conv.bias, out_nchw=True)

@@ -1,0 +1,165 @@
+"""Drop-in for the reference's layers/SpatialTransformer.py: same module tree and parameter names
+(SURVEY.md 8(b)); tokens stay (B, HW, C) bf16 views end to end, q/k/v projections are fused into one GEMM,
+attention is the flash kernel of csrc/attention.hip reading heads in place, residual adds / biases / GEGLU live in
+GEMM epilogues.  No xformers, no einops, no permutes."""
+import torch
+from torch import nn
+
+from stable_diffusion_amd import engine as E
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def _as_ctx(context):
+    if context is None or isinstance(context, E.Act):
+        return context
+    return E.tokens_from_f32(context)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def run(self, a):
+        w = self.proj.weight
+        return E.gemm(a, E.packed_linear((w,), geglu=True), w.shape[0], bias=self.proj.bias, geglu=True)
+
+    def forward(self, x):
+        return _tokens_out(self.run(_tokens_in(x)), x)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, int(dim * mult)), nn.Dropout(dropout), nn.Linear(int(dim * mult), dim_out or dim))
+
+    def run(self, a, residual=None):
+        g = self.net[0].run(a)
+        lin = self.net[2]
+        return E.gemm(g, E.packed_linear((lin.weight,)), lin.weight.shape[0], bias=lin.bias, residual=residual)
+
+    def forward(self, x):
+        return _tokens_out(self.run(_tokens_in(x)), x)
+
+
+def _tokens_in(x):
+    return x if isinstance(x, E.Act) else E.tokens_from_f32(x)
+
+
+def _tokens_out(a, like):
+    if isinstance(like, E.Act):
+        return a
+    out = E.to_nchw(E.Act(a.buf, a.n, a.hw, 1, a.c, a.off))     # (B, C, T, 1) fp32
+    return out[:, :, :, 0].transpose(1, 2).contiguous()
+
+
+class MemoryEfficientCrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("head_dim 64 only (the reference hard-codes inner_dim = 64*heads)")
+        self.heads, self.dim_head = heads, dim_head
+        inner = 64 * heads
+        context_dim = context_dim or query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+        self.attention_op = None
+
+    def run(self, a, context=None, residual=None):
+        inner = 64 * self.heads
+        if context is None:          # self-attention: one fused q|k|v GEMM
+            qkv = E.gemm(a, E.packed_linear((self.to_q.weight, self.to_k.weight, self.to_v.weight)), 3 * inner)
+            q, k, v = qkv.cols(0, inner), qkv.cols(inner, inner), qkv.cols(2 * inner, inner)
+        else:
+            q = E.gemm(a, E.packed_linear((self.to_q.weight,)), inner)
+            kv = E.gemm(context, E.packed_linear((self.to_k.weight, self.to_v.weight)), 2 * inner)
+            k, v = kv.cols(0, inner), kv.cols(inner, inner)
+        o = E.attention(q, k, v, self.heads)
+        lin = self.to_out[0]
+        return E.gemm(o, E.packed_linear((lin.weight,)), lin.weight.shape[0], bias=lin.bias, residual=residual)
+
+    def forward(self, x, context=None, mask=None):
+        if mask is not None:
+            raise NotImplementedError
+        return _tokens_out(self.run(_tokens_in(x), _as_ctx(context)), x)
+
+
+class MemoryEfficientAttnBlock(nn.Module):
+    """VAE mid-block single-head attention, d = C (reference :98-161)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+        self.q = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.k = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.v = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.proj_out = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.attention_op = None
+
+    def run(self, a, out=None):
+        c = self.in_channels
+        xn = E.groupnorm(a, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
+        qk = E.gemm(xn, E.packed_linear((self.q.weight, self.k.weight)), 2 * c, bias=E.stacked_f32((self.q.bias, self.k.bias)))
+        o = E.vae_attention_core(qk, xn, E.packed_linear((self.v.weight,)), self.v.bias, c)
+        return E.gemm(o, E.packed_linear((self.proj_out.weight,)), c, bias=self.proj_out.bias, residual=a, out=out)
+
+    def forward(self, x):
+        return E.to_nchw(self.run(E.from_nchw(x)))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, context_dim=None):
+        super().__init__()
+        self.dim, self.n_heads, self.context_dim = dim, n_heads, context_dim
+        self.attn1 = MemoryEfficientCrossAttention(query_dim=dim, heads=n_heads, context_dim=None)
+        self.ff = FeedForward(dim)
+        self.attn2 = MemoryEfficientCrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+
+    def run(self, t, context=None, taps=None):
+        t = self.attn1.run(E.layernorm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps), None, residual=t)
+        if taps is not None:
+            taps["attn1"] = t
+        t = self.attn2.run(E.layernorm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps), context, residual=t)
+        if taps is not None:
+            taps["attn2"] = t
+        t = self.ff.run(E.layernorm(t, self.norm3.weight, self.norm3.bias, self.norm3.eps), residual=t)
+        if taps is not None:
+            taps["ff"] = t
+        return t
+
+    def forward(self, x, context=None):
+        return _tokens_out(self.run(_tokens_in(x), _as_ctx(context)), x)
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads):
+        super().__init__()
+        self.in_channels, self.n_heads = in_channels, n_heads
+        inner = n_heads * 64
+        self.norm = nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, context_dim=1024)])
+        self.proj_out = zero_module(nn.Linear(in_channels, inner))
+
+    def run(self, a, context=None, out=None, taps=None):
+        xn = E.groupnorm(a, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
+        t = E.gemm(xn, E.packed_linear((self.proj_in.weight,)), self.proj_in.weight.shape[0], bias=self.proj_in.bias)
+        t = self.transformer_blocks[0].run(t, context, taps)
+        return E.gemm(t, E.packed_linear((self.proj_out.weight,)), self.proj_out.weight.shape[0], bias=self.proj_out.bias,
+                      residual=a, out=out)
+
+    def forward(self, x, t_emb=None, context=None):
+        if isinstance(context, list):
+            context = context[0]
+        return E.to_nchw(self.run(E.from_nchw(x), _as_ctx(context)))

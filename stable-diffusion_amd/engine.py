@@ -1,0 +1,311 @@
+"""Host-side engine: NHWC-bf16 activation views, weight pre-pack cache and thin wrappers over the C-ABI.
+
+PyTorch is used for device memory (torch.empty), the current HIP stream and parameter storage only; all
+arithmetic runs in libsdmi355.so.  There is no fallback: a missing library raises (see _lib.load).
+"""
+import math
+import weakref
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise L.SdmiError("%s: tensor is on %s; the HIP path needs a cuda (ROCm) tensor and has no CPU fallback"
+                          % (what, t.device))
+
+
+class Act(object):
+    """(n, h, w, c) activation stored NHWC bf16: buf[n, h*w, ld_total], columns [off, off+c)."""
+    __slots__ = ("buf", "n", "h", "w", "c", "off")
+
+    def __init__(self, buf, n, h, w, c, off=0):
+        self.buf, self.n, self.h, self.w, self.c, self.off = buf, n, h, w, c, off
+
+    @property
+    def hw(self):
+        return self.h * self.w
+
+    @property
+    def ld(self):
+        return self.buf.shape[-1]
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + 2 * self.off
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def cols(self, off, c):
+        return Act(self.buf, self.n, self.h, self.w, c, self.off + off)
+
+
+def new_act(n, h, w, c, device):
+    return Act(torch.empty((n, h * w, c), dtype=BF16, device=device), n, h, w, c)
+
+
+def from_nchw(x):
+    """NCHW fp32 tensor -> Act (module boundary, SURVEY 8(b) tensor conventions)."""
+    _need_cuda(x, "from_nchw")
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    cpad = (c + 7) // 8 * 8
+    a = new_act(n, h, w, cpad, x.device)
+    if cpad != c:
+        a.buf.zero_()
+    L.call("sdmi_nchw_f32_to_nhwc_bf16", x.data_ptr(), a.ptr, n, c, h * w, a.ld, _stream())
+    a.c = c
+    return a
+
+
+def to_nchw(a):
+    out = torch.empty((a.n, a.c, a.h, a.w), dtype=torch.float32, device=a.device)
+    L.call("sdmi_nhwc_bf16_to_nchw_f32", a.ptr, out.data_ptr(), a.n, a.c, a.hw, a.ld, _stream())
+    return out
+
+
+def tokens_from_f32(x):
+    """(B, T, C) fp32 -> Act(n=B, h=1, w=T, c=C) bf16 (text context entering to_k / to_v)."""
+    _need_cuda(x, "tokens_from_f32")
+    x = x.contiguous().float()
+    b, t, c = x.shape
+    a = new_act(b, 1, t, c, x.device)
+    L.call("sdmi_f32_to_bf16_rows", x.data_ptr(), a.ptr, b * t, c, a.ld, _stream())
+    return a
+
+
+# --------------------------------------------------------------------------- weight pre-pack cache
+class _PackCache(object):
+    """Packed bf16 copies of parameters, rebuilt when a parameter's storage or version changes
+    (load_state_dict / .to(device)); parameter names and shapes are never touched (checkpoint row)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, params, tag, build):
+        key = (tag,) + tuple(id(p) for p in params)
+        sig = tuple((p.data_ptr(), p._version, p.device) for p in params)
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == sig and all(r() is p for r, p in zip(hit[1], params)):
+            return hit[2]
+        val = build()
+        self._d[key] = (sig, [weakref.ref(p) for p in params], val)
+        return val
+
+    def clear(self):
+        self._d.clear()
+
+
+PACK = _PackCache()
+
+
+def _f32c(p, what):
+    _need_cuda(p, what)
+    if p.dtype != torch.float32 or not p.is_contiguous():
+        raise L.SdmiError("%s: expected a contiguous fp32 parameter" % what)
+    return p
+
+
+def packed_conv3x3(weight):
+    def build():
+        w = _f32c(weight, "conv weight")
+        co, ci = w.shape[0], w.shape[1]
+        out = torch.empty((co, 9 * ci), dtype=BF16, device=w.device)
+        L.call("sdmi_pack_conv3x3", w.data_ptr(), out.data_ptr(), co, ci, _stream())
+        return out
+    return PACK.get((weight,), "c3", build)
+
+
+def packed_linear(weights, geglu=False):
+    """One or more (N_i, K[,1,1]) fp32 weights stacked along N -> bf16 [sum N_i][K]."""
+    weights = tuple(weights)
+
+    def build():
+        k = weights[0].shape[1]
+        ntot = sum(w.shape[0] for w in weights)
+        out = torch.empty((ntot, k), dtype=BF16, device=weights[0].device)
+        r = 0
+        for w in weights:
+            w = _f32c(w, "linear weight")
+            L.call("sdmi_pack_linear", w.data_ptr(), out.data_ptr() + 2 * r * k, w.shape[0], k, 1 if geglu else 0, _stream())
+            r += w.shape[0]
+        return out
+    return PACK.get(weights, "lg" if geglu else "l", build)
+
+
+def stacked_f32(params):
+    """Concatenate 1-D fp32 parameters (stacked biases of fused projections)."""
+    params = tuple(params)
+    return PACK.get(params, "cat", lambda: torch.cat([_f32c(p, "bias") for p in params]).contiguous())
+
+
+# --------------------------------------------------------------------------- ops
+def groupnorm(a, weight, bias, eps, silu, groups=32):
+    """GroupNorm(+SiLU): stats pass + apply pass (csrc/norm.hip)."""
+    dev = a.device
+    ss = torch.empty((a.n, a.c, 2), dtype=torch.float32, device=dev)
+    ws = torch.empty((L.load().sdmi_groupnorm_ws_bytes(a.n, a.hw, a.c) // 4,), dtype=torch.float32, device=dev)
+    st = _stream()
+    L.call("sdmi_groupnorm_stats", a.ptr, a.n, a.hw, a.c, a.ld, groups, _f32c(weight, "gn weight").data_ptr(),
+           _f32c(bias, "gn bias").data_ptr(), float(eps), ss.data_ptr(), ws.data_ptr(), st)
+    y = new_act(a.n, a.h, a.w, a.c, dev)
+    L.call("sdmi_groupnorm_apply", a.ptr, a.ld, ss.data_ptr(), y.ptr, y.ld, a.n, a.hw, a.c, L.F_SILU if silu else 0, st)
+    return y
+
+
+def layernorm(a, weight, bias, eps=1e-5):
+    y = new_act(a.n, a.h, a.w, a.c, a.device)
+    L.call("sdmi_layernorm", a.ptr, a.ld, _f32c(weight, "ln weight").data_ptr(), _f32c(bias, "ln bias").data_ptr(),
+           float(eps), y.ptr, y.ld, a.n * a.hw, a.c, _stream())
+    return y
+
+
+def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias=None, ldrb=0, residual=None,
+            out=None, out_nchw=False):
+    """3x3 conv. pad = (left, right, top, bottom) as F.pad takes it. rowbias: fp32 tensor/ptr (per-sample channel add)."""
+    wp = packed_conv3x3(weight)
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cin != a.c:
+        raise L.SdmiError("conv3x3: input has %d channels, weight expects %d" % (a.c, cin))
+    pl, pr, pt, pb = pad
+    hin, win = (a.h * 2, a.w * 2) if upsample else (a.h, a.w)
+    ho = (hin + pt + pb - 3) // stride + 1
+    wo = (win + pl + pr - 3) // stride + 1
+    flags = 0
+    if bias is not None:
+        flags |= L.F_BIAS
+    if upsample:
+        flags |= L.F_UPSAMPLE2X
+    rb_ptr = 0
+    if rowbias is not None:
+        flags |= L.F_ROWBIAS
+        rb_ptr = rowbias if isinstance(rowbias, int) else rowbias.data_ptr()
+    res_ptr, ldr = 0, 0
+    if residual is not None:
+        flags |= L.F_RESIDUAL
+        res_ptr, ldr = residual.ptr, residual.ld
+    if out_nchw:
+        flags |= L.F_OUT_NCHW_F32
+        res = torch.empty((a.n, cout, ho, wo), dtype=torch.float32, device=a.device)
+        optr, ldc = res.data_ptr(), 0
+    else:
+        res = out if out is not None else new_act(a.n, ho, wo, cout, a.device)
+        optr, ldc = res.ptr, res.ld
+    L.call("sdmi_conv3x3", a.ptr, a.ld, a.n, a.h, a.w, cin, wp.data_ptr(), cout, ho, wo, stride, pt, pl,
+           _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags, _stream())
+    return res
+
+
+def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shape=None):
+    """Token GEMM: rows = n*hw of `a`, W packed [n_out][a.c]. Returns an Act with c = n_out (or n_out/2 for GEGLU)."""
+    m = a.n * a.hw
+    cres = n_out // 2 if geglu else n_out
+    res = out if out is not None else new_act(a.n, a.h, a.w, cres, a.device)
+    flags = 0
+    if bias is not None:
+        flags |= L.F_BIAS
+    if geglu:
+        flags |= L.F_GEGLU
+    res_ptr, ldr = 0, 0
+    if residual is not None:
+        flags |= L.F_RESIDUAL
+        res_ptr, ldr = residual.ptr, residual.ld
+    L.call("sdmi_gemm", a.ptr, a.ld, 0, wp.data_ptr(), wp.shape[1], 0, res.ptr, res.ld, 0, m, n_out, a.c, 1,
+           _ptr(bias), 0, 0, a.hw, res_ptr, ldr, 1.0, flags, _stream())
+    return res
+
+
+def attention(q, k, v, heads, out=None):
+    """softmax(q k^T / 8) v per head; q/k/v are column views (Act.cols) of token buffers."""
+    o = out if out is not None else new_act(q.n, q.h, q.w, heads * 64, q.device)
+    L.call("sdmi_attention", q.ptr, q.ld, q.hw * q.ld, k.ptr, k.ld, k.hw * k.ld, v.ptr, v.ld, v.hw * v.ld,
+           o.ptr, o.ld, o.hw * o.ld, q.n, heads, q.hw, k.hw, 0.125, _stream())
+    return o
+
+
+def linear_small_m(x, wp, bias, silu_in=False):
+    """fp32 (M<=64, K) x bf16 [N][K] -> fp32 (M, N)."""
+    m, k = x.shape
+    n = wp.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    L.call("sdmi_linear_small_m", x.data_ptr(), wp.data_ptr(), _ptr(bias), out.data_ptr(), m, n, k,
+           L.F_SILU if silu_in else 0, _stream())
+    return out
+
+
+_FREQS = {}
+
+
+def timestep_embedding(t, dim, max_period=10000):
+    """Unet.py:7-25 on device; the frequency table is the host fp32 expression of the reference."""
+    _need_cuda(t, "timestep_embedding")
+    half = dim // 2
+    key = (t.device, half, max_period)
+    if key not in _FREQS:
+        f = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+        _FREQS[key] = f.to(t.device)
+    t = t.to(torch.int64).contiguous()
+    out = torch.zeros((t.shape[0], dim), dtype=torch.float32, device=t.device) if dim % 2 else \
+        torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    if dim % 2:
+        raise L.SdmiError("timestep_embedding: odd dim unsupported")
+    L.call("sdmi_timestep_embedding", t.data_ptr(), _FREQS[key].data_ptr(), out.data_ptr(), t.shape[0], half, _stream())
+    return out
+
+
+def vae_attention_core(qk, xn, wv_packed, bv, c):
+    """Single-head attention over hw tokens with d = c (VAE mid block, layers/SpatialTransformer.py:140-158) as
+    score GEMM -> row softmax -> value GEMM, chunked over images.  qk: Act with q in cols [0,c), k in [c,2c);
+    xn: the normalised input (V is produced transposed, [c][hw], so the value GEMM reads it K-contiguous; V's bias is
+    added after the product since softmax rows sum to 1)."""
+    n, hw, dev = qk.n, qk.hw, qk.device
+    hwp = (hw + 7) // 8 * 8
+    o = new_act(n, qk.h, qk.w, c, dev)
+    per = max(1, min(n, int((1 << 31) // (hw * hwp * 4))))
+    st = _stream()
+    alloc = torch.zeros if hwp != hw else torch.empty
+    s = torch.empty((per, hw, hwp), dtype=torch.float32, device=dev)
+    p = alloc((per, hw, hwp), dtype=BF16, device=dev)
+    vt = alloc((per, c, hwp), dtype=BF16, device=dev)
+    scale = float(c) ** -0.5
+    for i0 in range(0, n, per):
+        nb = min(per, n - i0)
+        img = lambda act: act.ptr + 2 * i0 * act.hw * act.ld
+        # V^T[c][hw] = Wv[c][:] . xn[hw][:]
+        L.call("sdmi_gemm", wv_packed.data_ptr(), c, 0, img(xn), xn.ld, hw * xn.ld, vt.data_ptr(), hwp, c * hwp,
+               c, hw, c, nb, 0, 0, 0, 0, 0, 0, 1.0, 0, st)
+        # S = q k^T (fp32, unscaled; the softmax applies 1/sqrt(c))
+        L.call("sdmi_gemm", img(qk), qk.ld, hw * qk.ld, img(qk) + 2 * c, qk.ld, hw * qk.ld, s.data_ptr(), hwp, hw * hwp,
+               hw, hw, c, nb, 0, 0, 0, 0, 0, 0, 1.0, L.F_OUT_F32, st)
+        L.call("sdmi_softmax_rows", s.data_ptr(), hwp, p.data_ptr(), hwp, nb * hw, hw, scale, st)
+        # O = P V + bv
+        L.call("sdmi_gemm", p.data_ptr(), hwp, hw * hwp, vt.data_ptr(), hwp, c * hwp, img(o), o.ld, hw * o.ld,
+               hw, c, hwp, nb, _ptr(bv), 0, 0, 0, 0, 0, 1.0, L.F_BIAS if bv is not None else 0, st)
+    return o
+
+
+def cfg_ddim_step(eps, x, noise, guidance, s1m, a_t, a_prev, sigma, temperature=1.0, x_out=None, pred_x0=None,
+                  xc_out=None):
+    """Fused CFG + DDIM update (LatentDiffusionInpainting.py:198-212). eps: (2b,4,h,w) fp32 [uncond|cond]."""
+    b = x.shape[0]
+    chw = x[0].numel()
+    if x_out is None:
+        x_out = torch.empty_like(x)
+    L.call("sdmi_cfg_ddim_step", eps.data_ptr(), x.data_ptr(), noise.data_ptr(), float(guidance), float(s1m), float(a_t),
+           float(a_prev), float(sigma), float(temperature), x_out.data_ptr(), _ptr(pred_x0), _ptr(xc_out),
+           0 if xc_out is None else xc_out.shape[1], b, chw, _stream())
+    return x_out

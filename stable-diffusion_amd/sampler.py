@@ -1,0 +1,94 @@
+"""DDIM + classifier-free-guidance sampling loop on the HIP path.
+
+Follows LatentDiffusionInpainting.sample (reference LatentDiffusionInpainting.py:137-230): same timestep
+selection, same schedule arithmetic and dtypes (:150-159), same per-step math (:198-212, fused into one
+kernel, csrc/cfg_ddim.hip), same decode + uint8 conversion (:223-230).  Differences in HOW: everything stays
+resident on the GPU (no GPUManager moves - 288 GB HBM), the UNet input (2b,9,h,w) is assembled once and only
+its 4 latent channels are rewritten each step by the update kernel, the per-step noise is injected by the
+caller (the reference draws it from the unseeded global RNG, :211), and the UNet step can be replayed from a
+HIP graph (shapes are static across steps)."""
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import engine as E
+
+SCALE_FACTOR = 0.18215
+
+
+def ddim_schedule(num_ddim_timesteps, eta=1.0, num_train=1000, linear_start=1e-4, linear_end=2e-2):
+    """Timesteps + coefficient tables with the reference's dtypes (fp32 alphas_cumprod, float64 prev/sigma)."""
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, num_train, dtype=torch.float64) ** 2
+    acp = partial(torch.tensor, dtype=torch.float32)(np.cumprod(1. - betas.numpy(), axis=0))
+    step = num_train // num_ddim_timesteps
+    ts = np.asarray(list(range(0, num_train, step))) + 1
+    if ts[-1] >= num_train:
+        raise IndexError("num_ddim_timesteps=%d selects timestep %d >= %d (the reference fails the same way, "
+                         "LatentDiffusionInpainting.py:156)" % (num_ddim_timesteps, ts[-1], num_train))
+    a_t = acp[ts]
+    a_prev = np.asarray([acp[0]] + acp[ts[:-1]].tolist())
+    sig = eta * np.sqrt((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev))
+    return ts, a_t, a_prev, sig, np.sqrt(1. - a_t)
+
+
+def _f32(v):
+    """The value torch.full((b,1,1,1), v) would hold (fp32 rounding of a tensor / numpy / python scalar)."""
+    return float(torch.full((1,), v).item()) if not torch.is_tensor(v) else float(v.float().item())
+
+
+class Sampler(object):
+    def __init__(self, unet, vae=None):
+        self.unet, self.vae = unet, vae
+        self._graph = None
+        self._gkey = None
+
+    # one UNet evaluation on the static buffers, eager or replayed
+    def _unet_step(self, xc, t_buf, cc, use_graph):
+        if not use_graph:
+            return self.unet(xc, timesteps=t_buf, context=cc)
+        key = (xc.data_ptr(), t_buf.data_ptr(), cc.data_ptr(), tuple(xc.shape))
+        if self._gkey != key:
+            self.unet(xc, timesteps=t_buf, context=cc)          # warm-up: weight pre-pack, allocator pools
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.unet(xc, timesteps=t_buf, context=cc)
+            self._graph, self._gout, self._gkey = g, out, key
+        self._graph.replay()
+        return self._gout
+
+    @torch.no_grad()
+    def sample(self, num_ddim_timesteps, cond, uncond, c_concat, x_T, noises, scale, eta=1.0, temperature=1.0,
+               decode=True, use_graph=False, trace=None):
+        """cond/uncond (b,77,1024), c_concat (b,5,h,w), x_T (b,4,h,w), noises: sequence of (b,4,h,w) in loop order;
+        all fp32 cuda tensors.  Returns (latent, uint8 images (b,H,W,3) or None)."""
+        ts, a_t, a_prev, sig, s1m = ddim_schedule(num_ddim_timesteps, eta)
+        total = ts.shape[0]
+        b, _, h, w = x_T.shape
+        dev = x_T.device
+        xc = torch.empty((2 * b, 4 + c_concat.shape[1], h, w), dtype=torch.float32, device=dev)
+        xc[:b, :4] = x_T
+        xc[b:, :4] = x_T
+        xc[:b, 4:] = c_concat
+        xc[b:, 4:] = c_concat
+        cc = torch.cat([uncond, cond]).contiguous()
+        t_buf = torch.empty((2 * b,), dtype=torch.long, device=dev)
+        x = x_T.clone()
+        for i, step in enumerate(np.flip(ts)):
+            index = total - i - 1
+            t_buf.fill_(int(step))
+            eps = self._unet_step(xc, t_buf, cc, use_graph)
+            E.cfg_ddim_step(eps, x, noises[i], scale, _f32(s1m[index]), _f32(a_t[index]), _f32(a_prev[index]),
+                            _f32(sig[index]), temperature, x_out=x, xc_out=xc)
+            if trace is not None:
+                trace.append(x.clone())
+        if not decode:
+            return x, None
+        return x, self.decode_to_uint8(x)
+
+    @torch.no_grad()
+    def decode_to_uint8(self, latent):
+        out = self.vae.decode(1. / SCALE_FACTOR * latent)
+        img = torch.clamp((out + 1.0) / 2.0, min=0.0, max=1.0)
+        return (img.permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous()
