@@ -10,9 +10,9 @@
  *   - all pointers are DEVICE pointers owned by the caller; the library allocates nothing.
  *     Scratch space comes in through explicit workspace arguments.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.
- *   - activations: "NHWC bf16" = [N][H*W][C] row-major with row stride ld (elements, multiple of 8);
+ *   - activations: "NHWC h16" (h16 = the build's 16-bit type, see sdmi_act_dtype()) = [N][H*W][C] row-major with row stride ld (elements, multiple of 8);
  *     this is also the (B, tokens, C) layout of the transformer blocks, so no permutes exist.
- *   - packed weights: bf16 [N_out][K], K contiguous (for a 3x3 conv K = (ky*3+kx)*Cin + c).
+ *   - packed weights: h16 [N_out][K], K contiguous (for a 3x3 conv K = (ky*3+kx)*Cin + c).
  */
 #ifndef SDMI_H
 #define SDMI_H
@@ -36,6 +36,8 @@ extern "C" {
 #define SDMI_F_OUT_F32 128u /* gemm: store fp32 row-major (ldc in elements) instead of bf16  */
 
 int sdmi_version(void);
+/* 16-bit storage type ("h16") of activations and packed weights this build uses: 0 = IEEE fp16 (default), 1 = bf16 */
+int sdmi_act_dtype(void);
 const char* sdmi_last_error(void);
 
 /* ---- weight pre-pack (run once per parameter, after load_state_dict) ---------------------- */
@@ -46,10 +48,10 @@ int sdmi_pack_conv3x3(const float* w_oihw, void* w_packed, int cout, int cin, vo
 int sdmi_pack_linear(const float* w, void* w_packed, int n, int k, int geglu, void* stream);
 
 /* ---- layout at the module boundary (reference tensors are NCHW fp32: SURVEY 8(b)) ---------- */
-int sdmi_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int hw, int ldd, void* stream);
-int sdmi_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int hw, int lds, void* stream);
+int sdmi_nchw_f32_to_nhwc_h16(const float* src, void* dst, int n, int c, int hw, int ldd, void* stream);
+int sdmi_nhwc_h16_to_nchw_f32(const void* src, float* dst, int n, int c, int hw, int lds, void* stream);
 /* fp32 [rows][cols] -> bf16 [rows][ld]  (text context (B,77,1024) entering to_k / to_v) */
-int sdmi_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int ld, void* stream);
+int sdmi_f32_to_h16_rows(const float* src, void* dst, int rows, int cols, int ld, void* stream);
 
 /* ---- GroupNorm(32) (+SiLU): nn.GroupNorm + nn.SiLU at layers/ResBlock.py:65-66,:72-73; Unet.py:104-106;
  *      AutoencoderKL.py:193-194; layers/SpatialTransformer.py:134,:212 ----------------------- */

@@ -276,6 +276,20 @@ def cfg_ddim_update(x, e_uncond, e_cond, scale, a_t, a_prev, sigma_t, sqrt_one_m
     return a_prev.sqrt() * pred_x0 + dir_xt + sigma_t * noise * temperature, pred_x0
 
 
+def cfg_ddim_update_np(x, e_uncond, e_cond, scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise, temperature=1.0):
+    """The same update as IEEE fp32 arithmetic, one rounding per operation, in numpy (no vectorised-FMA or
+    host-dependent kernel choices): the bit-exact target of csrc/cfg_ddim.hip.  Equals cfg_ddim_update() bit for
+    bit in the build container; torch CPU builds on other hosts may differ from it in the last ulp."""
+    F = np.float32
+    r = lambda v: F(torch.full((1,), v).item())
+    x, eu, ec, nz = (np.asarray(t, dtype=np.float32) for t in (x, e_uncond, e_cond, noise))
+    a_t, a_prev, sg, s1m = r(a_t), r(a_prev), r(sigma_t), r(sqrt_one_minus_at)
+    e = eu + F(scale) * (ec - eu)
+    pred_x0 = (x - s1m * e) / np.sqrt(a_t)
+    dir_xt = np.sqrt(F(1.0) - a_prev - sg * sg) * e
+    return np.sqrt(a_prev) * pred_x0 + dir_xt + sg * nz * F(temperature), pred_x0
+
+
 def sample(sd_unet, sd_vae, num_ddim_timesteps, cond, uncond, c_concat, x_T, noises, scale, eta=1.0,
            decode=True, trace=None):
     """LatentDiffusionInpainting.sample (:137-230) with the per-step randn injected (``noises[i]`` is the

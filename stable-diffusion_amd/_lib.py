@@ -17,12 +17,13 @@ _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 # name -> (restype, argtypes); mirrors include/sdmi.h declaration by declaration
 PROTOTYPES = {
     "sdmi_version": (_i, []),
+    "sdmi_act_dtype": (_i, []),
     "sdmi_last_error": (C.c_char_p, []),
     "sdmi_pack_conv3x3": (_i, [_vp, _vp, _i, _i, _vp]),
     "sdmi_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "sdmi_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "sdmi_nhwc_bf16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "sdmi_f32_to_bf16_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sdmi_nchw_f32_to_nhwc_h16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sdmi_nhwc_h16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sdmi_f32_to_h16_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sdmi_groupnorm_ws_bytes": (_i64, [_i, _i, _i]),
     "sdmi_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "sdmi_groupnorm_apply": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _u32, _vp]),

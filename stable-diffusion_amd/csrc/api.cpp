@@ -22,5 +22,10 @@ int sdmi_check_launch(const char* what) {
   return SDMI_OK;
 }
 
-extern "C" int sdmi_version(void) { return 100; }
+extern "C" int sdmi_version(void) { return 101; }
+#ifdef SDMI_BF16
+extern "C" int sdmi_act_dtype(void) { return 1; }
+#else
+extern "C" int sdmi_act_dtype(void) { return 0; }
+#endif
 extern "C" const char* sdmi_last_error(void) { return g_err; }

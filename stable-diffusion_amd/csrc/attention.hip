@@ -37,9 +37,9 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
 
   const int qrow = blockIdx.x * 128 + wv * 32 + r;
   const int qrc = qrow < p.nq ? qrow : p.nq - 1;
-  bf16x8 qf[4];
+  hx8 qf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const hx8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
 
   // staging: 64 rows x 8 chunks of 16 B per tile and operand; thread -> (row = t>>3 (+32), chunk = t&7)
   const int chunk = t & 7, r0 = t >> 3;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
     for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 a = *(const bf16x8*)&sK[k_off(32 * kt2 + r, 2 * ks + hh)];
-        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kt2], 0, 0, 0);
+        const hx8 a = *(const hx8*)&sK[k_off(32 * kt2 + r, 2 * ks + hh)];
+        s[kt2] = MFMA32(a, qf[ks], s[kt2], 0, 0, 0);
       }
     // ---- online softmax, query on the lane ----
     const bool tail = kv0 + 64 > p.nkv;
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
     for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 pb;
+        hx8 pb;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[kt2][8 * s2 + j];
+        for (int j = 0; j < 8; ++j) pb[j] = (h16)s[kt2][8 * s2 + j];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int c = 4 * dt + 2 * dblk + (tp >> 1);
@@ -137,10 +137,10 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
               (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0, c) + 4 * (tp & 1)));
           const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0 + 8, c) + 4 * (tp & 1)));
-          union { struct { short4_t a, b; } h; bf16x8 v; } u;
+          union { struct { short4_t a, b; } h; hx8 v; } u;
           u.h.a = lo;
           u.h.b = hi;
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pb, oacc[dt], 0, 0, 0);
+          oacc[dt] = MFMA32(u.v, pb, oacc[dt], 0, 0, 0);
         }
       }
     __syncthreads();
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * dt + 8 * g + 4 * hh;
-        const uint2 o2 = make_uint2(pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
-                                    pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv));
+        const uint2 o2 = make_uint2(pack2h(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
+                                    pack2h(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv));
         *(uint2*)(O + (long long)qrow * p.ldo + d) = o2;
       }
   }

@@ -5,11 +5,25 @@
 #include "sdmi.h"
 
 typedef unsigned short u16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16-bit storage type of activations and packed weights ("h16" in the ABI).  fp16 by default: same MFMA rate as
+// bf16 on gfx950 and 3 more mantissa bits, which is what the parity-vs-fp32 budget needs; -DSDMI_BF16 selects bf16.
+#ifdef SDMI_BF16
+typedef __bf16 h16;
+#define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#define SDMI_ACT_DTYPE 1
+#else
+typedef _Float16 h16;
+#define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#define SDMI_ACT_DTYPE 0
+#endif
+typedef h16 hx8 __attribute__((ext_vector_type(8)));
+typedef h16 hx2 __attribute__((ext_vector_type(2)));
 
 // host side: error reporting (defined in api.cpp)
 void sdmi_set_error(const char* fmt, ...);
@@ -23,20 +37,31 @@ int sdmi_check_launch(const char* what);
     }                                      \
   } while (0)
 
-__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ u16 f2bf(float f) {
-  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
-  return __builtin_bit_cast(u16, b);
+__device__ __forceinline__ float h2f(u16 v) { return (float)__builtin_bit_cast(h16, v); }
+__device__ __forceinline__ h16 f2h16(float f) {
+#ifdef SDMI_BF16
+  return (h16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+#else
+  return (h16)__builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f);  // saturate instead of +-inf
+#endif
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ u16 f2h(float f) { return __builtin_bit_cast(u16, f2h16(f)); }
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+  hx2 v;
+  v[0] = f2h16(lo);
+  v[1] = f2h16(hi);
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+  const hx2 v = __builtin_bit_cast(hx2, w);
+  lo = (float)v[0];
+  hi = (float)v[1];
+}
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
-  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  unpack2(v.x, f[0], f[1]); unpack2(v.y, f[2], f[3]); unpack2(v.z, f[4], f[5]); unpack2(v.w, f[6], f[7]);
 }
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
-  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+  return make_uint4(pack2h(f[0], f[1]), pack2h(f[2], f[3]), pack2h(f[4], f[5]), pack2h(f[6], f[7]));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float wave_sum(float v) {

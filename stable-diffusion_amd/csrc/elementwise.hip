@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int px = p0 + i, ch = c0 + tx;
-    if (px < hw && ch < c) dst[((long long)n * hw + px) * ldd + ch] = f2bf(tile[tx][i]);
+    if (px < hw && ch < c) dst[((long long)n * hw + px) * ldd + ch] = f2h(tile[tx][i]);
   }
 }
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const u16* __restrict__ src, float* __restrict__ dst, int c, int hw, int lds) {
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const u16* __restrict
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8) {
     const int px = p0 + i, ch = c0 + tx;
-    tile[i][tx] = (px < hw && ch < c) ? bf2f(src[((long long)n * hw + px) * lds + ch]) : 0.f;
+    tile[i][tx] = (px < hw && ch < c) ? h2f(src[((long long)n * hw + px) * lds + ch]) : 0.f;
   }
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
@@ -32,13 +32,13 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const u16* __restrict
     if (ch < c && px < hw) dst[((long long)n * c + ch) * hw + px] = tile[tx][i];
   }
 }
-extern "C" int sdmi_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int hw, int ldd, void* stream) {
+extern "C" int sdmi_nchw_f32_to_nhwc_h16(const float* src, void* dst, int n, int c, int hw, int ldd, void* stream) {
   SDMI_REQUIRE(src && dst && n > 0 && c > 0 && hw > 0 && ldd >= c && n <= 65535, "nchw_to_nhwc: bad argument");
   dim3 grid((hw + 31) / 32, (c + 31) / 32, n);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, c, hw, ldd);
   return sdmi_check_launch("nchw_to_nhwc");
 }
-extern "C" int sdmi_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int hw, int lds, void* stream) {
+extern "C" int sdmi_nhwc_h16_to_nchw_f32(const void* src, float* dst, int n, int c, int hw, int lds, void* stream) {
   SDMI_REQUIRE(src && dst && n > 0 && c > 0 && hw > 0 && lds >= c && n <= 65535, "nhwc_to_nchw: bad argument");
   dim3 grid((hw + 31) / 32, (c + 31) / 32, n);
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)src, dst, c, hw, lds);
@@ -49,10 +49,10 @@ __global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const float* __re
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / cols;
     const int cidx = (int)(i - r * cols);
-    dst[r * ld + cidx] = f2bf(src[i]);
+    dst[r * ld + cidx] = f2h(src[i]);
   }
 }
-extern "C" int sdmi_f32_to_bf16_rows(const float* src, void* dst, int rows, int cols, int ld, void* stream) {
+extern "C" int sdmi_f32_to_h16_rows(const float* src, void* dst, int rows, int cols, int ld, void* stream) {
   SDMI_REQUIRE(src && dst && rows > 0 && cols > 0 && ld >= cols, "f32_to_bf16_rows: bad argument");
   const long long total = (long long)rows * cols;
   long long nb = (total + 255) / 256;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
     const long long r = i / cin;
     const int tap = (int)(r % 9);
     const long long co = r / 9;
-    o[i] = f2bf(w[(co * cin + ci) * 9 + tap]);
+    o[i] = f2h(w[(co * cin + ci) * 9 + tap]);
   }
 }
 __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, u16* __restrict__ o, int n, int k, int geglu, long long total) {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
       const int s = (int)((row >> 4) & 1), j = (int)(row & 15);
       srow = (s ? (long long)(n >> 1) : 0) + 16 * b + j;
     }
-    o[i] = f2bf(w[srow * k + kk]);
+    o[i] = f2h(w[srow * k + kk]);
   }
 }
 extern "C" int sdmi_pack_conv3x3(const float* w_oihw, void* w_packed, int cout, int cin, void* stream) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv3x3_in_kernel(const float* __restrict
   }
   u16* op = out + ((long long)n * hw + pix) * ldc + cg * 8;
   if (cg * 8 + 7 < cout) *(uint4*)op = pack8(o);
-  else for (int e = 0; e < 8; ++e) if (cg * 8 + e < cout) op[e] = f2bf(o[e]);
+  else for (int e = 0; e < 8; ++e) if (cg * 8 + e < cout) op[e] = f2h(o[e]);
 }
 extern "C" int sdmi_conv3x3_in(const float* x_nchw, int n, int cin, int h, int w, const float* w_oihw, const float* bias,
                                int cout, void* out, int ldc, void* stream) {
@@ -211,9 +211,9 @@ __global__ void timestep_embedding_kernel(const long long* __restrict__ t, const
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m * half) return;
   const int r = i / half, j = i - r * half;
-  const float a = (float)t[r] * freqs[j];
-  out[(long long)r * 2 * half + j] = cosf(a);
-  out[(long long)r * 2 * half + half + j] = sinf(a);
+  const float a = (float)t[r] * freqs[j];  // fp32 product as in the reference; the trig in fp64 then rounds once
+  out[(long long)r * 2 * half + j] = (float)cos((double)a);
+  out[(long long)r * 2 * half + half + j] = (float)sin((double)a);
 }
 extern "C" int sdmi_timestep_embedding(const int64_t* t, const float* freqs, float* out, int m, int half, void* stream) {
   SDMI_REQUIRE(t && freqs && out && m > 0 && half > 0, "timestep_embedding: bad argument");

@@ -128,15 +128,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ch = lq + 4 * kk;
-      bf16x8 af[MT], wf[NT];
+      hx8 af[MT], wf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)&cA[lds_off(wr * (BM / 2) + i * 16 + l15, ch)];
+      for (int i = 0; i < MT; ++i) af[i] = *(const hx8*)&cA[lds_off(wr * (BM / 2) + i * 16 + l15, ch)];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)&cB[lds_off(wc * (BN / 2) + j * 16 + l15, ch)];
+      for (int j = 0; j < NT; ++j) wf[j] = *(const hx8*)&cB[lds_off(wc * (BN / 2) + j * 16 + l15, ch)];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           y[e] = xv * gelu_erf(gv);
         }
         u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + oc;
-        *(uint2*)o = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+        *(uint2*)o = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
       }
       continue;
     }
@@ -188,10 +188,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const u16* r = p.res + (long long)bz * p.sc + (long long)m * p.ldr + n0;
         if (full) {
           const uint2 rv = *(const uint2*)r;
-          y[0] += __uint_as_float(rv.x << 16); y[1] += __uint_as_float(rv.x & 0xffff0000u);
-          y[2] += __uint_as_float(rv.y << 16); y[3] += __uint_as_float(rv.y & 0xffff0000u);
+          float r0, r1, r2, r3;
+          unpack2(rv.x, r0, r1);
+          unpack2(rv.y, r2, r3);
+          y[0] += r0; y[1] += r1; y[2] += r2; y[3] += r3;
         } else {
-          for (int e = 0; e < 4; ++e) if (n0 + e < p.N) y[e] += bf2f(r[e]);
+          for (int e = 0; e < 4; ++e) if (n0 + e < p.N) y[e] += h2f(r[e]);
         }
       }
       if (fl & SDMI_F_OUT_NCHW_F32) {
@@ -204,8 +206,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = y[e];
       } else {
         u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + n0;
-        if (full) *(uint2*)o = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
-        else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = f2bf(y[e]);
+        if (full) *(uint2*)o = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
+        else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = f2h(y[e]);
       }
     }
   }

@@ -284,11 +284,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
   for (int i = t; i < c4; i += 256) {
     const float4 v = ((const float4*)xr)[i];
-    const uint2 o = make_uint2(pack2bf(__builtin_amdgcn_exp2f(v.x * scale_log2 - mx) * inv, __builtin_amdgcn_exp2f(v.y * scale_log2 - mx) * inv),
-                               pack2bf(__builtin_amdgcn_exp2f(v.z * scale_log2 - mx) * inv, __builtin_amdgcn_exp2f(v.w * scale_log2 - mx) * inv));
+    const uint2 o = make_uint2(pack2h(__builtin_amdgcn_exp2f(v.x * scale_log2 - mx) * inv, __builtin_amdgcn_exp2f(v.y * scale_log2 - mx) * inv),
+                               pack2h(__builtin_amdgcn_exp2f(v.z * scale_log2 - mx) * inv, __builtin_amdgcn_exp2f(v.w * scale_log2 - mx) * inv));
     ((uint2*)yr)[i] = o;
   }
-  for (int i = c4 * 4 + t; i < cols; i += 256) yr[i] = f2bf(__builtin_amdgcn_exp2f(xr[i] * scale_log2 - mx) * inv);
+  for (int i = c4 * 4 + t; i < cols; i += 256) yr[i] = f2h(__builtin_amdgcn_exp2f(xr[i] * scale_log2 - mx) * inv);
 }
 
 extern "C" int sdmi_softmax_rows(const float* x, int ldx, void* y, int ldy, int rows, int cols, float scale, void* stream) {

@@ -160,7 +160,7 @@ def _padded_1x1(weight, kpad):
     co, ci = weight.shape[0], weight.shape[1]
     w = torch.zeros((co, kpad), dtype=torch.float32, device=weight.device)
     w[:, :ci] = weight.reshape(co, ci)
-    out = torch.empty((co, kpad), dtype=torch.bfloat16, device=weight.device)
+    out = torch.empty((co, kpad), dtype=E.act_dtype(), device=weight.device)
     E.L.call("sdmi_pack_linear", w.data_ptr(), out.data_ptr(), co, kpad, 0, E._stream())
     return out
 

@@ -10,7 +10,12 @@ import torch
 
 from . import _lib as L
 
-BF16 = torch.bfloat16
+
+
+def act_dtype():
+    """torch dtype of the library's 16-bit storage type (fp16 unless built with -DSDMI_BF16)."""
+    return torch.bfloat16 if L.load().sdmi_act_dtype() == 1 else torch.float16
+
 
 
 def _stream():
@@ -55,7 +60,7 @@ class Act(object):
 
 
 def new_act(n, h, w, c, device):
-    return Act(torch.empty((n, h * w, c), dtype=BF16, device=device), n, h, w, c)
+    return Act(torch.empty((n, h * w, c), dtype=act_dtype(), device=device), n, h, w, c)
 
 
 def from_nchw(x):
@@ -67,14 +72,14 @@ def from_nchw(x):
     a = new_act(n, h, w, cpad, x.device)
     if cpad != c:
         a.buf.zero_()
-    L.call("sdmi_nchw_f32_to_nhwc_bf16", x.data_ptr(), a.ptr, n, c, h * w, a.ld, _stream())
+    L.call("sdmi_nchw_f32_to_nhwc_h16", x.data_ptr(), a.ptr, n, c, h * w, a.ld, _stream())
     a.c = c
     return a
 
 
 def to_nchw(a):
     out = torch.empty((a.n, a.c, a.h, a.w), dtype=torch.float32, device=a.device)
-    L.call("sdmi_nhwc_bf16_to_nchw_f32", a.ptr, out.data_ptr(), a.n, a.c, a.hw, a.ld, _stream())
+    L.call("sdmi_nhwc_h16_to_nchw_f32", a.ptr, out.data_ptr(), a.n, a.c, a.hw, a.ld, _stream())
     return out
 
 
@@ -84,7 +89,7 @@ def tokens_from_f32(x):
     x = x.contiguous().float()
     b, t, c = x.shape
     a = new_act(b, 1, t, c, x.device)
-    L.call("sdmi_f32_to_bf16_rows", x.data_ptr(), a.ptr, b * t, c, a.ld, _stream())
+    L.call("sdmi_f32_to_h16_rows", x.data_ptr(), a.ptr, b * t, c, a.ld, _stream())
     return a
 
 
@@ -124,7 +129,7 @@ def packed_conv3x3(weight):
     def build():
         w = _f32c(weight, "conv weight")
         co, ci = w.shape[0], w.shape[1]
-        out = torch.empty((co, 9 * ci), dtype=BF16, device=w.device)
+        out = torch.empty((co, 9 * ci), dtype=act_dtype(), device=w.device)
         L.call("sdmi_pack_conv3x3", w.data_ptr(), out.data_ptr(), co, ci, _stream())
         return out
     return PACK.get((weight,), "c3", build)
@@ -137,7 +142,7 @@ def packed_linear(weights, geglu=False):
     def build():
         k = weights[0].shape[1]
         ntot = sum(w.shape[0] for w in weights)
-        out = torch.empty((ntot, k), dtype=BF16, device=weights[0].device)
+        out = torch.empty((ntot, k), dtype=act_dtype(), device=weights[0].device)
         r = 0
         for w in weights:
             w = _f32c(w, "linear weight")
@@ -256,7 +261,9 @@ def timestep_embedding(t, dim, max_period=10000):
     half = dim // 2
     key = (t.device, half, max_period)
     if key not in _FREQS:
-        f = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+        # exp(-ln(max_period) i/half) evaluated in fp64 and rounded once: the same table on every host (torch's
+        # fp32 exp differs in the last ulp between CPU back ends, which moves cos(t*f) by up to ~6e-5 at t ~ 1000)
+        f = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float64) / half).float()
         _FREQS[key] = f.to(t.device)
     t = t.to(torch.int64).contiguous()
     out = torch.zeros((t.shape[0], dim), dtype=torch.float32, device=t.device) if dim % 2 else \
@@ -279,8 +286,8 @@ def vae_attention_core(qk, xn, wv_packed, bv, c):
     st = _stream()
     alloc = torch.zeros if hwp != hw else torch.empty
     s = torch.empty((per, hw, hwp), dtype=torch.float32, device=dev)
-    p = alloc((per, hw, hwp), dtype=BF16, device=dev)
-    vt = alloc((per, c, hwp), dtype=BF16, device=dev)
+    p = alloc((per, hw, hwp), dtype=act_dtype(), device=dev)
+    vt = alloc((per, c, hwp), dtype=act_dtype(), device=dev)
     scale = float(c) ** -0.5
     for i0 in range(0, n, per):
         nb = min(per, n - i0)

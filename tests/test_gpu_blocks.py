@@ -1,0 +1,135 @@
+"""GPU: drop-in modules against the committed golden vectors captured from the reference's own modules
+(tests/golden, oracle/make_golden.py) and whole-network parity against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import sd_oracle as O
+from conftest import rel_err
+from stable_diffusion_amd.synth import fill_state_dict, make_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = torch.from_numpy
+
+
+def _mod(m, seed):
+    fill_state_dict(m.state_dict(), seed=seed)
+    return m.to(DEV).eval()
+
+
+def _tol():
+    from stable_diffusion_amd import engine as E
+    return 8.0 if E.act_dtype() == torch.bfloat16 else 1.0
+
+
+def _check(got, ref, max_tol, l2_tol, what):
+    """Gates (fp16 build) are ~3x the error measured on MI355X; the bf16 build scales them by 8."""
+    max_tol, l2_tol = max_tol * _tol(), l2_tol * _tol()
+    m, l2 = rel_err(got.float().cpu().numpy(), np.asarray(ref))
+    print("%s: max-rel %.3e  rel-L2 %.3e" % (what, m, l2))
+    assert m <= max_tol and l2 <= l2_tol, (what, m, l2)
+
+
+def test_resblock_golden(golden):
+    from layers.ResBlock import ResBlock
+    g = golden("g1_resblock")
+    for name, (cin, cout, temb) in {"rb_a": (64, 128, 256), "rb_b": (128, 128, 0)}.items():
+        m = _mod(ResBlock(cin, cout, temb), 11)
+        t = T(g[name + "_t"]).to(DEV) if temb else None
+        _check(m(T(g[name + "_x"]).to(DEV), t_emb=t), g[name + "_y"], 2e-3, 1.5e-3, "ResBlock " + name)
+
+
+def test_spatial_transformer_golden(golden):
+    from layers.SpatialTransformer import SpatialTransformer
+    from stable_diffusion_amd import engine as E
+    g = golden("g2_spatial_transformer")
+    m = _mod(SpatialTransformer(128, 2), 12)
+    x, ctx = T(g["x"]).to(DEV), T(g["ctx"]).to(DEV)
+    _check(m(x, context=ctx), g["y"], 3e-3, 2e-3, "SpatialTransformer")
+    taps = {}
+    m.run(E.from_nchw(x), E.tokens_from_f32(ctx), taps=taps)
+    for k in ("attn1", "attn2", "ff"):
+        _check(taps[k].buf, g[k], 3e-3, 2e-3, "  tap " + k)
+
+
+def test_vae_attn_updown_golden(golden):
+    from layers.SpatialTransformer import MemoryEfficientAttnBlock
+    from layers.ResBlock import Upsample, Downsample
+    g = golden("g3_vae_attn")
+    _check(_mod(MemoryEfficientAttnBlock(64), 13)(T(g["x"]).to(DEV)), g["y"], 2e-3, 1.2e-3, "MemoryEfficientAttnBlock")
+    g = golden("g4_updown")
+    x = T(g["x"]).to(DEV)
+    _check(_mod(Upsample(64), 14)(x), g["up_y"], 1.5e-3, 1.2e-3, "Upsample")
+    _check(_mod(Downsample(64), 15)(x), g["down_y"], 1.5e-3, 1.2e-3, "Downsample")
+    _check(_mod(Downsample(64, padding=(0, 1, 0, 1)), 16)(x), g["down_enc_y"], 1.5e-3, 1.2e-3, "Downsample enc")
+
+
+def test_vae_golden_and_encode(golden):
+    from AutoencoderKL import AutoencoderKL
+    g = golden("g6_vae")
+    vae = _mod(AutoencoderKL(), 1)
+    _check(vae.decode(T(g["z"]).to(DEV)), g["y"], 6e-3, 5e-3, "AutoencoderKL.decode L=8")
+    _check(vae.encode(T(g["img"]).to(DEV)).parameters, g["moments"], 6e-3, 5e-3, "AutoencoderKL.encode 32x32")
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from Unet import Unet
+    from AutoencoderKL import AutoencoderKL
+    unet = Unet()
+    sd_u = fill_state_dict(unet.state_dict(), seed=0)
+    sd_u = {k: v.clone() for k, v in sd_u.items()}     # CPU copy for the oracle
+    vae = AutoencoderKL()
+    sd_v = {k: v.clone() for k, v in fill_state_dict(vae.state_dict(), seed=1).items()}
+    return unet.to(DEV).eval(), vae.to(DEV).eval(), sd_u, sd_v
+
+
+def test_unet_golden(golden, nets):
+    unet = nets[0]
+    g = golden("g6_unet")
+    y = unet(T(g["x"]).to(DEV), timesteps=T(g["t"]).to(DEV), context=T(g["ctx"]).to(DEV))
+    _check(y, g["y"], 7e-3, 6e-3, "Unet.forward L=8 (golden from the reference)")
+
+
+def test_ddim_trajectory_golden(golden, nets):
+    """4-step DDIM + CFG trajectory of the reference's own sample() with injected noise: per-step latent error and
+    final-image PSNR (tolerances of the north star: stated here)."""
+    from stable_diffusion_amd.sampler import Sampler
+    unet, vae = nets[0], nets[1]
+    g7 = golden("g7_ddim")
+    steps, L, b, scale = int(g7["steps"]), int(g7["L"]), int(g7["b"]), float(g7["scale"])
+    inp = make_inputs(b, L, steps, seed=100)
+    dev = lambda t: t.to(DEV)
+    trace = []
+    x, img = Sampler(unet, vae).sample(steps, dev(inp["cond"]), dev(inp["uncond"]), dev(inp["c_concat"]), dev(inp["x_T"]),
+                                       [dev(n) for n in inp["noises"]], scale, trace=trace)
+    for i in range(steps):
+        _check(trace[i], g7["traj"][i], 1.5e-2, 1.5e-2, "latent after step %d" % i)
+    mse = np.mean((img.cpu().numpy().astype(np.float64) - g7["image"].astype(np.float64)) ** 2)
+    psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    print("final image PSNR vs reference: %.2f dB" % psnr)
+    assert psnr >= (40.0 if _tol() == 1.0 else 30.0)
+
+
+def test_unet_256px_vs_oracle_and_batch_invariance(nets):
+    """L=32 (256x256) CFG batch: HIP vs the CPU oracle; and a batch of 2 images equals the two images run alone,
+    bit for bit (images never interact; the multi-GPU sharding relies on it)."""
+    unet, _, sd_u, _ = nets
+    rs = np.random.RandomState(5)
+    x = T(rs.randn(2, 9, 32, 32).astype(np.float32))
+    ctx = T(rs.randn(2, 77, 1024).astype(np.float32))
+    t = torch.tensor([501, 501], dtype=torch.long)
+    ref = O.unet_forward(sd_u, x, t, ctx)
+    y = unet(x.to(DEV), timesteps=t.to(DEV), context=ctx.to(DEV))
+    _check(y, ref.numpy(), 7e-3, 6e-3, "Unet.forward L=32 vs oracle")
+    y0 = unet(x[:1].to(DEV), timesteps=t[:1].to(DEV), context=ctx[:1].to(DEV))
+    y1 = unet(x[1:].to(DEV), timesteps=t[1:].to(DEV), context=ctx[1:].to(DEV))
+    assert torch.equal(torch.cat([y0, y1]), y)
+    assert torch.equal(unet(x.to(DEV), timesteps=t.to(DEV), context=ctx.to(DEV)), y)      # run-to-run deterministic
+
+
+def test_vae_decode_256px_vs_oracle(nets):
+    _, vae, _, sd_v = nets
+    z = T(np.random.RandomState(6).randn(1, 4, 32, 32).astype(np.float32))
+    _check(vae.decode(z.to(DEV)), O.vae_decode(sd_v, z).numpy(), 7e-3, 5e-3, "decode L=32 vs oracle")

@@ -104,3 +104,14 @@ def test_unet_full_and_ddim(golden):
     for i in range(steps):
         np.testing.assert_allclose(trace[i].numpy(), g7["traj"][i], rtol=0, atol=2e-3)
     assert np.abs(img.astype(np.int32) - g7["image"].astype(np.int32)).max() <= 1
+
+
+def test_cfg_ddim_numpy_restatement_equals_torch_restatement():
+    rs = np.random.RandomState(8)
+    x, eu, ec, nz = (T(rs.randn(2, 4, 8, 8).astype(np.float32)) for _ in range(4))
+    sch = O.ddim_schedule(50)
+    for index in (0, 17, 49):
+        args = (x, eu, ec, 9.0, sch["alphas"][index], sch["alphas_prev"][index], sch["sigmas"][index], sch["sqrt_one_minus_alphas"][index], nz)
+        a, a0 = O.cfg_ddim_update(*args)
+        b, b0 = O.cfg_ddim_update_np(*args)
+        assert np.abs(a.numpy() - b).max() <= 1e-6 * np.abs(b).max() and np.abs(a0.numpy() - b0).max() <= 1e-6 * np.abs(b0).max()
