@@ -60,9 +60,51 @@ def load():
     return _lib
 
 
+# Optional per-entry-point timing (bench.py's roofline leg): when set to a KernelTimer, every call is bracketed
+# by HIP events recorded on the stream the kernel is launched on.
+TIMER = None
+
+
+class KernelTimer(object):
+    """Collects (entry point, algorithmic work, event pair) for every C-ABI call made while installed."""
+
+    def __init__(self, work_fn):
+        self.work_fn, self.records = work_fn, []
+
+    def __enter__(self):
+        global TIMER
+        TIMER = self
+        return self
+
+    def __exit__(self, *exc):
+        global TIMER
+        TIMER = None
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, work, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += work[0]
+            d["bytes"] += work[1]
+        return out
+
+
 def call(name, *args):
     """Invoke an int-returning entry point; raise SdmiError(sdmi_last_error()) on a non-zero code."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if TIMER is not None:
+        import torch
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        rc = getattr(lib, name)(*args)
+        e1.record(st)
+        TIMER.records.append((name, TIMER.work_fn(name, args), e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise SdmiError("%s -> %d: %s" % (name, rc, lib.sdmi_last_error().decode()))

@@ -22,6 +22,8 @@ struct AttnParams {
   float scale_log2;
 };
 
+__device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4] = {0u, 0u, 0u, 0u};
+
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 1) << 2)) << 3); }
 
@@ -41,26 +43,27 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const hx8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
 
-  // staging: 64 rows x 8 chunks of 16 B per tile and operand; thread -> (row = t>>3 (+32), chunk = t&7)
+  // staging: 64 rows x 8 chunks of 16 B per tile and operand; thread -> (row = t>>3 (+32), chunk = t&7).
+  // Keys past nkv read a 16-byte zero page (unconditional loads: they stay in flight across the MFMAs).
   const int chunk = t & 7, r0 = t >> 3;
-  uint4 rk[2], rv[2];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  auto load_tile = [&](int kv0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = kv0 + r0 + 32 * i;
-      const bool ok = key < p.nkv;
-      rk[i] = ok ? *(const uint4*)(K + (long long)key * p.ldk + chunk * 8) : zero4;
-      rv[i] = ok ? *(const uint4*)(V + (long long)key * p.ldv + chunk * 8) : zero4;
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *(uint4*)&sK[k_off(r0 + 32 * i, chunk)] = rk[i];
-      *(uint4*)&sV[v_off(r0 + 32 * i, chunk)] = rv[i];
-    }
-  };
+  u32x4 rk0, rk1, rv0, rv1;
+  const u16* const zp = (const u16*)g_attn_zero16;
+#define ATTN_LOAD_TILE(KV0)                                                                   \
+  {                                                                                           \
+    const int key0 = (KV0) + r0, key1 = (KV0) + r0 + 32;                                      \
+    const bool ok0 = key0 < p.nkv, ok1 = key1 < p.nkv;                                        \
+    rk0 = *(const u32x4*)(ok0 ? K + (long long)key0 * p.ldk + chunk * 8 : zp);                \
+    rv0 = *(const u32x4*)(ok0 ? V + (long long)key0 * p.ldv + chunk * 8 : zp);                \
+    rk1 = *(const u32x4*)(ok1 ? K + (long long)key1 * p.ldk + chunk * 8 : zp);                \
+    rv1 = *(const u32x4*)(ok1 ? V + (long long)key1 * p.ldv + chunk * 8 : zp);                \
+  }
+#define ATTN_STORE_TILE()                                  \
+  {                                                        \
+    *(u32x4*)&sK[k_off(r0, chunk)] = rk0;                  \
+    *(u32x4*)&sV[v_off(r0, chunk)] = rv0;                  \
+    *(u32x4*)&sK[k_off(r0 + 32, chunk)] = rk1;             \
+    *(u32x4*)&sV[v_off(r0 + 32, chunk)] = rv1;             \
+  }
 
   f32x16 oacc[2];
 #pragma unroll
@@ -71,12 +74,12 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
   const int dblk = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
 
   const int ntiles = (p.nkv + 63) / 64;
-  load_tile(0);
+  ATTN_LOAD_TILE(0);
   for (int tile = 0; tile < ntiles; ++tile) {
     const int kv0 = tile * 64;
-    store_tile();
+    ATTN_STORE_TILE();
     __syncthreads();
-    if (tile + 1 < ntiles) load_tile(kv0 + 64);
+    if (tile + 1 < ntiles) ATTN_LOAD_TILE(kv0 + 64);
 
     // ---- S^T[key][q] ----
     f32x16 s[2];

@@ -7,6 +7,7 @@
 typedef unsigned short u16;
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // 16-bit storage type of activations and packed weights ("h16" in the ABI).  fp16 by default: same MFMA rate as

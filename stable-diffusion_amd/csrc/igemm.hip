@@ -26,6 +26,8 @@ struct IgemmParams {
   int nk;
 };
 
+__device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};  // non-const: stays in the global address space (no flat loads)
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
 
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       a_ptr[i] = A + (long long)img * p.H * p.W * p.lda;
     } else {
       a_oy[i] = a_ox[i] = 0;
-      a_ptr[i] = A + (long long)gmc * p.lda + chunk * 8;
+      a_ptr[i] = A + (long long)gmc * p.lda;
     }
   }
   bool b_ok[PB];
@@ -70,45 +72,55 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   for (int i = 0; i < PB; ++i) {
     const int gn = bcol + r0 + 32 * i;
     b_ok[i] = gn < p.N;
-    b_ptr[i] = Wp + (long long)(b_ok[i] ? gn : 0) * p.ldw + chunk * 8;
+    b_ptr[i] = Wp + (long long)(b_ok[i] ? gn : 0) * p.ldw;
   }
 
-  uint4 ra[PA], rb[PB];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  // Out-of-range rows / taps / k-chunks read 16 zero bytes from g_zero16 instead of being predicated: every
+  // global load is unconditional, so the loads of tile k+1 stay in flight across the MFMAs of tile k (a
+  // predicated load makes hipcc wait for it inside its own branch).
+  u32x4 ra[PA], rb[PB];
+  const u16* const zp = (const u16*)g_zero16;
   int tap = 0, cb = 0;  // CONV: position of the NEXT tile to load
 
-  auto load_tile = [&](int kt) {
-    if constexpr (CONV) {
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      const int c = cb * 64 + chunk * 8;
-      const bool cok = c < p.Cin;
-      const int hlim = p.H << p.ups, wlim = p.W << p.ups;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        int iy = a_oy[i] * p.stride + ky - p.pad_t, ix = a_ox[i] * p.stride + kx - p.pad_l;
-        const bool ok = a_ok[i] && cok && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
-        iy >>= p.ups;
-        ix >>= p.ups;
-        ra[i] = ok ? *(const uint4*)(a_ptr[i] + ((long long)(iy * p.W + ix) * p.lda + c)) : zero4;
-      }
-      const int wk = tap * p.Cin + c - chunk * 8;  // b_ptr already carries chunk*8
-#pragma unroll
-      for (int i = 0; i < PB; ++i) rb[i] = (b_ok[i] && cok) ? *(const uint4*)(b_ptr[i] + wk) : zero4;
-      if (++cb == p.kt_per_tap) { cb = 0; ++tap; }
-    } else {
-      const bool kok = kt * 64 + chunk * 8 < p.K;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = (a_ok[i] && kok) ? *(const uint4*)(a_ptr[i] + kt * 64) : zero4;
-#pragma unroll
-      for (int i = 0; i < PB; ++i) rb[i] = (b_ok[i] && kok) ? *(const uint4*)(b_ptr[i] + kt * 64) : zero4;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < PA; ++i) *(uint4*)&sA[buf * BM * 64 + lds_off(r0 + 32 * i, chunk)] = ra[i];
-#pragma unroll
-    for (int i = 0; i < PB; ++i) *(uint4*)&sB[buf * BN * 64 + lds_off(r0 + 32 * i, chunk)] = rb[i];
-  };
+#define IGEMM_LOAD_TILE(KT)                                                                                       \
+  {                                                                                                               \
+    if constexpr (CONV) {                                                                                         \
+      const int ky = tap / 3, kx = tap - 3 * ky;                                                                  \
+      const int c = cb * 64 + chunk * 8;                                                                          \
+      const bool cok = c < p.Cin;                                                                                 \
+      const int hlim = p.H << p.ups, wlim = p.W << p.ups;                                                         \
+      _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                            \
+        int iy = a_oy[i] * p.stride + ky - p.pad_t, ix = a_ox[i] * p.stride + kx - p.pad_l;                       \
+        const bool ok = a_ok[i] && cok && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;                           \
+        iy >>= p.ups;                                                                                             \
+        ix >>= p.ups;                                                                                             \
+        const u16* src = ok ? a_ptr[i] + ((long long)(iy * p.W + ix) * p.lda + c) : zp;                           \
+        ra[i] = *(const u32x4*)src;                                                                               \
+      }                                                                                                           \
+      const int wk = tap * p.Cin + c;                                                                             \
+      _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                            \
+        const u16* src = (b_ok[i] && cok) ? b_ptr[i] + wk : zp;                                                   \
+        rb[i] = *(const u32x4*)src;                                                                               \
+      }                                                                                                           \
+      if (++cb == p.kt_per_tap) { cb = 0; ++tap; }                                                                \
+    } else {                                                                                                      \
+      const int ko = (KT) * 64 + chunk * 8;                                                                       \
+      const bool kok = ko < p.K;                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                            \
+        const u16* src = (a_ok[i] && kok) ? a_ptr[i] + ko : zp;                                                   \
+        ra[i] = *(const u32x4*)src;                                                                               \
+      }                                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                            \
+        const u16* src = (b_ok[i] && kok) ? b_ptr[i] + ko : zp;                                                   \
+        rb[i] = *(const u32x4*)src;                                                                               \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+#define IGEMM_STORE_TILE(BUF)                                                                                     \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < PA; ++i) *(u32x4*)&sA[(BUF) * BM * 64 + lds_off(r0 + 32 * i, chunk)] = ra[i]; \
+    _Pragma("unroll") for (int i = 0; i < PB; ++i) *(u32x4*)&sB[(BUF) * BN * 64 + lds_off(r0 + 32 * i, chunk)] = rb[i]; \
+  }
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -116,13 +128,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
-  store_tile(0);
+  IGEMM_LOAD_TILE(0);
+  IGEMM_STORE_TILE(0);
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < p.nk; ++kt) {
     const bool more = kt + 1 < p.nk;
-    if (more) load_tile(kt + 1);
+    if (more) IGEMM_LOAD_TILE(kt + 1);
     const u16* cA = sA + cur * BM * 64;
     const u16* cB = sB + cur * BN * 64;
 #pragma unroll
@@ -138,10 +150,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(cur ^ 1);
+    if (more) IGEMM_STORE_TILE(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
+#undef IGEMM_LOAD_TILE
+#undef IGEMM_STORE_TILE
 
   // ---- epilogue: lane holds out[m][n0..n0+3], m = tile row l15, n0 = 4*lq within each 16x16 tile ----
   const uint32_t fl = p.flags;

@@ -8,6 +8,7 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------ GroupNorm
+__device__ __attribute__((aligned(16))) unsigned g_norm_zero16[4] = {0u, 0u, 0u, 0u};
 // pass 1a: per-block partial (sum, sumsq) of every group.  grid (nblk, N); a wave reads whole rows
 // (lane -> 8-channel chunk lane, lane+64, ...), keeps per-channel sums in registers, the 4 waves
 // combine through LDS in wave order, then thread g folds the channels of group g.
@@ -26,18 +27,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const u16* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[s][e] = b[s][e] = 0.f;
   const u16* base = x + (long long)n * hw * ldx;
-  for (int row = row_beg + wv; row < row_end; row += 4) {
-    const u16* rp = base + (long long)row * ldx;
+  const u16* const zp = (const u16*)g_norm_zero16;
+  // 4 rows per wave in flight per iteration; rows past the block / chunks past C read a zero page (adds 0)
+  for (int row = row_beg + wv; row < row_end; row += 16) {
+    u32x4 v[4][NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int ch = lane + 64 * s;
-      if (ch < cc) {
+    for (int j = 0; j < 4; ++j) {
+      const int rr = row + 4 * j;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int ch = lane + 64 * s;
+        v[j][s] = *(const u32x4*)((rr < row_end && ch < cc) ? base + (long long)rr * ldx + ch * 8 : zp);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
         float f[8];
-        unpack8(*(const uint4*)(rp + ch * 8), f);
+        unpack8(make_uint4(v[j][s][0], v[j][s][1], v[j][s][2], v[j][s][3]), f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { a[s][e] += f[e]; b[s][e] += f[e] * f[e]; }
       }
-    }
   }
   for (int w = 0; w < 4; ++w) {
     if (wv == w) {
@@ -131,8 +142,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x
 }
 
 static int gn_nblk(int hw) {
-  int nb = (hw + 63) / 64;
-  return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+  int nb = (hw + 31) / 32;
+  return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
 }
 
 extern "C" int64_t sdmi_groupnorm_ws_bytes(int n, int hw, int c) {
