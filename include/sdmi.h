@@ -77,7 +77,13 @@ int sdmi_layernorm(const void* x, int ldx, const float* gamma, const float* beta
  *   optional 2x upsample (input pixel = (oy*stride+ky-pad_t, ox*stride+kx-pad_l), zero outside).   */
 int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout,
                  int hout, int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias,
-                 int ldrb, const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* stream);
+                 int ldrb, const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* ws, int64_t ws_bytes,
+                 void* stream);
+/* bytes of split-K workspace sdmi_conv3x3 can use for this problem (0 = never splits).  Under-filled grids (few
+ * output tiles, long K: the 12x12 / 24x24 UNet levels) are cut along K into fp32 partials that a second kernel sums in
+ * a fixed order and finishes with the epilogue.  The factor depends only on the per-sample shape, so results do not
+ * depend on the batch.  Passing ws = NULL (or too few bytes) disables the split. */
+int64_t sdmi_conv3x3_ws_bytes(int n, int cin, int cout, int hout, int wout);
 
 /* ---- first-layer conv with tiny Cin reading the caller's NCHW fp32 tensor directly:
  *      Unet.py:49 (9->320), AutoencoderKL.py:136 (4->512), :61 (3->128).  w is the fp32 OIHW weight. */
@@ -91,7 +97,9 @@ int sdmi_conv3x3_in(const float* x_nchw, int n, int cin, int h, int w, const flo
  *      to its sample for SDMI_F_ROWBIAS. */
 int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
               int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
-              int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* stream);
+              int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* ws,
+              int64_t ws_bytes, void* stream);
+int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags);
 
 /* ---- skinny linear for M <= 64 rows: Unet.time_embed (Unet.py:41-45) and every ResBlock.emb_proj
  *      (layers/ResBlock.py:70) batched into one launch. x fp32 [M][K]; w bf16 [N][K]; out fp32 [M][N];

@@ -28,9 +28,11 @@ PROTOTYPES = {
     "sdmi_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "sdmi_groupnorm_apply": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _u32, _vp]),
     "sdmi_layernorm": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
-    "sdmi_conv3x3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp]),
+    "sdmi_conv3x3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp, _i64, _vp]),
+    "sdmi_conv3x3_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "sdmi_conv3x3_in": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
-    "sdmi_gemm": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp]),
+    "sdmi_gemm": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp, _i64, _vp]),
+    "sdmi_gemm_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _u32]),
     "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
     "sdmi_timestep_embedding": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),

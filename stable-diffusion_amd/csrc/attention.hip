@@ -27,7 +27,7 @@ __device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4] = {0u, 0u, 0u,
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 1) << 2)) << 3); }
 
-__global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) u16 sK[64 * 64];
   __shared__ __attribute__((aligned(16))) u16 sV[64 * 64];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hh = lane >> 5;

@@ -11,6 +11,7 @@
 // issued before the MFMAs of tile k and written to the other LDS buffer after them (one barrier per
 // K-tile).  v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand, so a lane ends up with 4
 // consecutive output channels of one pixel (8-byte bf16 stores, 16-byte fp32 bias loads).
+#include <stdlib.h>
 #include "common.h"
 
 struct IgemmParams {
@@ -24,12 +25,77 @@ struct IgemmParams {
   // conv geometry (CONV only)
   int H, W, Cin, Ho, Wo, stride, pad_t, pad_l, ups, kt_per_tap;
   int nk;
+  // split-K: grid.z splits of kt_per_split K-tiles each write fp32 partials [split][batch][M][npad] to ws
+  int splits, kt_per_split, npad;
+  float* ws;
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};  // non-const: stays in the global address space (no flat loads)
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+
+// Finish 4 consecutive output channels n0..n0+3 of row m (alpha, bias, per-sample bias, residual) and store them in
+// the requested layout.  Shared by the GEMM kernel's register epilogue and the split-K reduce kernel.
+__device__ __forceinline__ void epilogue4(const IgemmParams& p, int bz, int m, int n0, float (&y)[4]) {
+  const uint32_t fl = p.flags;
+  const int hwo = p.rows_per_sample;
+  const bool full = n0 + 3 < p.N;
+  int sample = 0, pix = m;
+  if (fl & (SDMI_F_ROWBIAS | SDMI_F_OUT_NCHW_F32)) { sample = m / hwo; pix = m - sample * hwo; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    y[e] *= p.alpha;
+    const int n = (full || n0 + e < p.N) ? n0 + e : n0;
+    if (fl & SDMI_F_BIAS) y[e] += p.bias[n];
+    if (fl & SDMI_F_ROWBIAS) y[e] += p.rowbias[(long long)sample * p.ldrb + n];
+  }
+  if (fl & SDMI_F_RESIDUAL) {
+    const u16* r = p.res + (long long)bz * p.sc + (long long)m * p.ldr + n0;
+    if (full) {
+      const uint2 rv = *(const uint2*)r;
+      float r0, r1, r2, r3;
+      unpack2(rv.x, r0, r1);
+      unpack2(rv.y, r2, r3);
+      y[0] += r0; y[1] += r1; y[2] += r2; y[3] += r3;
+    } else {
+      for (int e = 0; e < 4; ++e) if (n0 + e < p.N) y[e] += h2f(r[e]);
+    }
+  }
+  if (fl & SDMI_F_OUT_NCHW_F32) {
+    float* o = (float*)p.out + ((long long)sample * p.N + n0) * hwo + pix;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (full || n0 + e < p.N) o[(long long)e * hwo] = y[e];
+  } else if (fl & SDMI_F_OUT_F32) {
+    float* o = (float*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + n0;
+    if (full) *(float4*)o = make_float4(y[0], y[1], y[2], y[3]);
+    else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = y[e];
+  } else {
+    u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + n0;
+    if (full) *(uint2*)o = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
+    else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = f2h(y[e]);
+  }
+}
+
+// split-K second pass: sum the fp32 partials in split order (deterministic) and run the epilogue.
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmParams p, int batch) {
+  const int nq = p.npad >> 2;
+  const long long per_split = (long long)batch * p.M * p.npad;
+  const long long total = (long long)batch * p.M * nq;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int q = (int)(i % nq);
+    const long long r = i / nq;
+    const int m = (int)(r % p.M), bz = (int)(r / p.M);
+    const float* src = p.ws + r * p.npad + q * 4;
+    float4 a = *(const float4*)src;
+    for (int s = 1; s < p.splits; ++s) {
+      const float4 b = *(const float4*)(src + s * per_split);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float y[4] = {a.x, a.y, a.z, a.w};
+    epilogue4(p, bz, m, q * 4, y);
+  }
+}
 
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
@@ -80,7 +146,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // predicated load makes hipcc wait for it inside its own branch).
   u32x4 ra[PA], rb[PB];
   const u16* const zp = (const u16*)g_zero16;
-  int tap = 0, cb = 0;  // CONV: position of the NEXT tile to load
+  const int kt_begin = blockIdx.z * p.kt_per_split;
+  const int kt_end = min(p.nk, kt_begin + p.kt_per_split);
+  int tap = kt_begin / p.kt_per_tap, cb = kt_begin - tap * p.kt_per_tap;  // CONV: position of the NEXT tile to load
 
 #define IGEMM_LOAD_TILE(KT)                                                                                       \
   {                                                                                                               \
@@ -128,12 +196,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  IGEMM_LOAD_TILE(0);
+  IGEMM_LOAD_TILE(kt_begin);
   IGEMM_STORE_TILE(0);
   __syncthreads();
   int cur = 0;
-  for (int kt = 0; kt < p.nk; ++kt) {
-    const bool more = kt + 1 < p.nk;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = kt + 1 < kt_end;
     if (more) IGEMM_LOAD_TILE(kt + 1);
     const u16* cA = sA + cur * BM * 64;
     const u16* cB = sB + cur * BN * 64;
@@ -159,13 +227,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   // ---- epilogue: lane holds out[m][n0..n0+3], m = tile row l15, n0 = 4*lq within each 16x16 tile ----
   const uint32_t fl = p.flags;
-  const int hwo = p.rows_per_sample;
+  if (p.splits > 1) {  // raw fp32 partials; igemm_splitk_reduce_kernel finishes
+    float* wsb = p.ws + ((long long)blockIdx.z * gridDim.y + bz) * p.M * p.npad;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = brow + wr * (BM / 2) + i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n0 = bcol + wc * (BN / 2) + j * 16 + lq * 4;
+        if (n0 < p.npad) *(float4*)(wsb + (long long)m * p.npad + n0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = brow + wr * (BM / 2) + i * 16 + l15;
     if (m >= p.M) continue;
-    int sample = 0, pix = m;
-    if (fl & (SDMI_F_ROWBIAS | SDMI_F_OUT_NCHW_F32)) { sample = m / hwo; pix = m - sample * hwo; }
     if (fl & SDMI_F_GEGLU) {
       const int half = p.N >> 1;
 #pragma unroll
@@ -189,68 +268,82 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int j = 0; j < NT; ++j) {
       const int n0 = bcol + wc * (BN / 2) + j * 16 + lq * 4;
       if (n0 >= p.N) continue;
-      const bool full = n0 + 3 < p.N;
-      float y[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        y[e] = acc[i][j][e] * p.alpha;
-        const int n = (full || n0 + e < p.N) ? n0 + e : n0;
-        if (fl & SDMI_F_BIAS) y[e] += p.bias[n];
-        if (fl & SDMI_F_ROWBIAS) y[e] += p.rowbias[(long long)sample * p.ldrb + n];
-      }
-      if (fl & SDMI_F_RESIDUAL) {
-        const u16* r = p.res + (long long)bz * p.sc + (long long)m * p.ldr + n0;
-        if (full) {
-          const uint2 rv = *(const uint2*)r;
-          float r0, r1, r2, r3;
-          unpack2(rv.x, r0, r1);
-          unpack2(rv.y, r2, r3);
-          y[0] += r0; y[1] += r1; y[2] += r2; y[3] += r3;
-        } else {
-          for (int e = 0; e < 4; ++e) if (n0 + e < p.N) y[e] += h2f(r[e]);
-        }
-      }
-      if (fl & SDMI_F_OUT_NCHW_F32) {
-        float* o = (float*)p.out + ((long long)sample * p.N + n0) * hwo + pix;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (full || n0 + e < p.N) o[(long long)e * hwo] = y[e];
-      } else if (fl & SDMI_F_OUT_F32) {
-        float* o = (float*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + n0;
-        if (full) *(float4*)o = make_float4(y[0], y[1], y[2], y[3]);
-        else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = y[e];
-      } else {
-        u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + n0;
-        if (full) *(uint2*)o = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
-        else for (int e = 0; e < 4; ++e) if (n0 + e < p.N) o[e] = f2h(y[e]);
-      }
+      float y[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue4(p, bz, m, n0, y);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------ host
+// Split-K factor.  Depends only on the PER-SAMPLE problem (rows_per_sample, N, K), never on the batch, so one image
+// produces the same bits whether it runs alone or inside a larger batch (the image-sharded multi-GPU path relies on
+// it).  Under-filled grids (few output tiles, long K) are cut so that >= ~384 blocks exist per sample.
+static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags) {
+  if (flags & SDMI_F_GEGLU) return 1;
+  static int target = -1;
+  if (target < 0) {
+    const char* e = getenv("SDMI_SPLITK_TARGET");
+    target = e ? atoi(e) : 384;
+  }
+  if (target <= 0) return 1;
+  const int bn = ((n % 128 == 0) || (n > 512)) ? 128 : 64;
+  const int bm = rows_per_sample >= 1024 ? 128 : 64;
+  const long long tiles = (long long)((rows_per_sample + bm - 1) / bm) * ((n + bn - 1) / bn);
+  if (tiles > 128) return 1;
+  long long s = target / tiles;
+  if (s > nk / 8) s = nk / 8;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int)s;
+}
+
+static int64_t splitk_ws_bytes(int m, int n, int nk, int batch, int rows_per_sample, uint32_t flags) {
+  const int s = splitk_factor(rows_per_sample, n, nk, flags);
+  if (s < 2) return 0;
+  const int kps = (nk + s - 1) / s;
+  const int splits = (nk + kps - 1) / kps;
+  return (int64_t)splits * batch * m * ((n + 3) / 4 * 4) * (int64_t)sizeof(float);
+}
+
 template <bool CONV>
-static int launch_igemm(const IgemmParams& p, int batch, hipStream_t st) {
+static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
   // tile choice: wide N tile unless N is small or would waste > ~1/6 of it; halve BM when the grid
   // would not cover the 256 CUs.
+  p.splits = 1;
+  p.kt_per_split = p.nk;
+  p.npad = (p.N + 3) / 4 * 4;
+  p.ws = nullptr;
+  const int s = splitk_factor(p.rows_per_sample, p.N, p.nk, p.flags);
+  if (s >= 2 && ws && ws_bytes >= splitk_ws_bytes(p.M, p.N, p.nk, batch, p.rows_per_sample, p.flags)) {
+    p.kt_per_split = (p.nk + s - 1) / s;
+    p.splits = (p.nk + p.kt_per_split - 1) / p.kt_per_split;
+    p.ws = (float*)ws;
+  }
   const bool bn128 = (p.N % 128 == 0) || (p.N > 512);
   const int bn = bn128 ? 128 : 64;
-  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * batch;
+  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * batch * p.splits;
   const bool bm128 = p.M > 64 && tiles128 >= 256;
   const int bm = bm128 ? 128 : 64;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-  dim3 grid(nb, batch), block(256);
+  dim3 grid(nb, batch, p.splits), block(256);
   if (bm128 && bn128) hipLaunchKernelGGL((igemm_kernel<128, 128, CONV>), grid, block, 0, st, p);
   else if (bm128) hipLaunchKernelGGL((igemm_kernel<128, 64, CONV>), grid, block, 0, st, p);
   else if (bn128) hipLaunchKernelGGL((igemm_kernel<64, 128, CONV>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((igemm_kernel<64, 64, CONV>), grid, block, 0, st, p);
-  return sdmi_check_launch(CONV ? "conv3x3" : "gemm");
+  int rc = sdmi_check_launch(CONV ? "conv3x3" : "gemm");
+  if (rc || p.splits < 2) return rc;
+  long long items = (long long)batch * p.M * (p.npad / 4);
+  long long rb = (items + 255) / 256;
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), block, 0, st, p, batch);
+  return sdmi_check_launch("split-K reduce");
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
                          int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
-                         int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* stream) {
+                         int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* ws,
+                         int64_t ws_bytes, void* stream) {
   SDMI_REQUIRE(a && w && out, "gemm: null pointer");
   SDMI_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0, "gemm: bad shape m=%d n=%d k=%d batch=%d", m, n, k, batch);
   SDMI_REQUIRE(k % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k, "gemm: k/lda/ldw must be multiples of 8 (k=%d lda=%d ldw=%d)", k, lda, ldw);
@@ -269,14 +362,16 @@ extern "C" int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int 
   IgemmParams p = {};
   p.a = (const u16*)a; p.w = (const u16*)w; p.out = out; p.bias = bias; p.rowbias = rowbias; p.res = (const u16*)residual;
   p.sa = sa; p.sw = sw; p.sc = sc; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
-  p.M = m; p.N = n; p.K = k; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.alpha = alpha; p.flags = flags;
+  p.M = m; p.N = n; p.K = k; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : m; p.alpha = alpha; p.flags = flags;
   p.nk = (k + 63) / 64;
-  return launch_igemm<false>(p, batch, (hipStream_t)stream);
+  p.kt_per_tap = 1;
+  return launch_igemm<false>(p, batch, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout, int hout,
                             int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias, int ldrb,
-                            const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* stream) {
+                            const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* ws, int64_t ws_bytes,
+                            void* stream) {
   SDMI_REQUIRE(x && w_packed && out, "conv3x3: null pointer");
   SDMI_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && hout > 0 && wout > 0, "conv3x3: bad shape");
   SDMI_REQUIRE(cin % 8 == 0 && ldx % 8 == 0 && ldx >= cin, "conv3x3: cin and ldx must be multiples of 8 (cin=%d ldx=%d)", cin, ldx);
@@ -298,5 +393,15 @@ extern "C" int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin
   p.H = h; p.W = w; p.Cin = cin; p.Ho = hout; p.Wo = wout; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.ups = ups;
   p.kt_per_tap = (cin + 63) / 64;
   p.nk = 9 * p.kt_per_tap;
-  return launch_igemm<true>(p, 1, (hipStream_t)stream);
+  return launch_igemm<true>(p, 1, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags) {
+  if (m <= 0 || n <= 0 || k <= 0 || batch <= 0) return 0;
+  return splitk_ws_bytes(m, n, (k + 63) / 64, batch, rows_per_sample > 0 ? rows_per_sample : m, flags);
+}
+
+extern "C" int64_t sdmi_conv3x3_ws_bytes(int n, int cin, int cout, int hout, int wout) {
+  if (n <= 0 || cin <= 0 || cout <= 0 || hout <= 0 || wout <= 0) return 0;
+  return splitk_ws_bytes(n * hout * wout, cout, 9 * ((cin + 63) / 64), 1, hout * wout, 0);
 }

@@ -151,7 +151,7 @@ def _conv1x1_nchw(x, conv):
     o = E.new_act(n, h, w, 8, x.device)
     o.buf.zero_()
     E.L.call("sdmi_gemm", a.ptr, a.ld, 0, wp.data_ptr(), wp.shape[1], 0, o.ptr, o.ld, 0, n * h * w, co, a.ld, 1,
-             conv.bias.data_ptr(), 0, 0, h * w, 0, 0, 1.0, E.L.F_BIAS, E._stream())
+             conv.bias.data_ptr(), 0, 0, h * w, 0, 0, 1.0, E.L.F_BIAS, 0, 0, E._stream())
     o.c = co
     return E.to_nchw(o)
 

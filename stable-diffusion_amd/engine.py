@@ -158,6 +158,22 @@ def stacked_f32(params):
     return PACK.get(params, "cat", lambda: torch.cat([_f32c(p, "bias") for p in params]).contiguous())
 
 
+# --------------------------------------------------------------------------- split-K workspace
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Per-device fp32 scratch for split-K partials, grown on demand (kernels on one stream run in order, so one
+    buffer serves every launch).  Returns (ptr, bytes); (0, 0) when nothing is needed."""
+    if nbytes <= 0:
+        return 0, 0
+    t = _WS.get(device)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty(((max(nbytes, 64 << 20) + 3) // 4,), dtype=torch.float32, device=device)
+        _WS[device] = t
+    return t.data_ptr(), t.numel() * 4
+
+
 # --------------------------------------------------------------------------- ops
 def groupnorm(a, weight, bias, eps, silu, groups=32):
     """GroupNorm(+SiLU): stats pass + apply pass (csrc/norm.hip)."""
@@ -210,8 +226,9 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
     else:
         res = out if out is not None else new_act(a.n, ho, wo, cout, a.device)
         optr, ldc = res.ptr, res.ld
+    ws, wsb = _workspace(a.device, L.load().sdmi_conv3x3_ws_bytes(a.n, cin, cout, ho, wo))
     L.call("sdmi_conv3x3", a.ptr, a.ld, a.n, a.h, a.w, cin, wp.data_ptr(), cout, ho, wo, stride, pt, pl,
-           _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags, _stream())
+           _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags, ws, wsb, _stream())
     return res
 
 
@@ -229,8 +246,9 @@ def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shap
     if residual is not None:
         flags |= L.F_RESIDUAL
         res_ptr, ldr = residual.ptr, residual.ld
+    ws, wsb = _workspace(a.device, L.load().sdmi_gemm_ws_bytes(m, n_out, a.c, 1, a.hw, flags))
     L.call("sdmi_gemm", a.ptr, a.ld, 0, wp.data_ptr(), wp.shape[1], 0, res.ptr, res.ld, 0, m, n_out, a.c, 1,
-           _ptr(bias), 0, 0, a.hw, res_ptr, ldr, 1.0, flags, _stream())
+           _ptr(bias), 0, 0, a.hw, res_ptr, ldr, 1.0, flags, ws, wsb, _stream())
     return res
 
 
@@ -294,14 +312,14 @@ def vae_attention_core(qk, xn, wv_packed, bv, c):
         img = lambda act: act.ptr + 2 * i0 * act.hw * act.ld
         # V^T[c][hw] = Wv[c][:] . xn[hw][:]
         L.call("sdmi_gemm", wv_packed.data_ptr(), c, 0, img(xn), xn.ld, hw * xn.ld, vt.data_ptr(), hwp, c * hwp,
-               c, hw, c, nb, 0, 0, 0, 0, 0, 0, 1.0, 0, st)
+               c, hw, c, nb, 0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, st)
         # S = q k^T (fp32, unscaled; the softmax applies 1/sqrt(c))
         L.call("sdmi_gemm", img(qk), qk.ld, hw * qk.ld, img(qk) + 2 * c, qk.ld, hw * qk.ld, s.data_ptr(), hwp, hw * hwp,
-               hw, hw, c, nb, 0, 0, 0, 0, 0, 0, 1.0, L.F_OUT_F32, st)
+               hw, hw, c, nb, 0, 0, 0, 0, 0, 0, 1.0, L.F_OUT_F32, 0, 0, st)
         L.call("sdmi_softmax_rows", s.data_ptr(), hwp, p.data_ptr(), hwp, nb * hw, hw, scale, st)
         # O = P V + bv
         L.call("sdmi_gemm", p.data_ptr(), hwp, hw * hwp, vt.data_ptr(), hwp, c * hwp, img(o), o.ld, hw * o.ld,
-               hw, c, hwp, nb, _ptr(bv), 0, 0, 0, 0, 0, 1.0, L.F_BIAS if bv is not None else 0, st)
+               hw, c, hwp, nb, _ptr(bv), 0, 0, 0, 0, 0, 1.0, L.F_BIAS if bv is not None else 0, 0, 0, st)
     return o
 
 

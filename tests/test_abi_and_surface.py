@@ -32,7 +32,8 @@ def test_argument_validation_returns_error_codes_without_gpu():
     lib = _lib.load()
     assert lib.sdmi_groupnorm_ws_bytes(2, 4096, 320) > 0
     # null pointers / bad shapes are rejected before any launch
-    assert lib.sdmi_gemm(None, 8, 0, None, 8, 0, None, 8, 0, 4, 4, 8, 1, None, None, 0, 0, None, 0, 1.0, 0, None) == -1
+    assert lib.sdmi_gemm(None, 8, 0, None, 8, 0, None, 8, 0, 4, 4, 8, 1, None, None, 0, 0, None, 0, 1.0, 0, None, 0, None) == -1
+    assert lib.sdmi_conv3x3_ws_bytes(2, 1280, 1280, 12, 12) > 0 and lib.sdmi_conv3x3_ws_bytes(1, 128, 128, 768, 768) == 0
     assert b"null" in lib.sdmi_last_error()
     assert lib.sdmi_attention(None, 64, 0, None, 64, 0, None, 64, 0, None, 64, 0, 1, 1, 4, 4, 0.125, None) == -1
     with pytest.raises(_lib.SdmiError):

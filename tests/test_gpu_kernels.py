@@ -213,3 +213,26 @@ def test_cfg_ddim_bit_exact():
         assert torch.equal(out.cpu(), ref), index
         assert torch.equal(p0.cpu(), ref0), index
         assert torch.equal(xc[:b, :4].cpu(), ref) and torch.equal(xc[b:, :4].cpu(), ref) and float(xc[:, 4:].abs().max()) == 0.0
+
+
+def test_splitk_conv_and_gemm_batch_invariant():
+    """Under-filled grids run split-K (fp32 partials + a fixed-order reduce): parity holds and one image gives the
+    same bits alone or inside a batch (the split factor depends on the per-sample shape only)."""
+    rs = _rs(77)
+    n, cin, cout, h = 2, 512, 256, 6
+    assert L.load().sdmi_conv3x3_ws_bytes(n, cin, cout, h, h) > 0
+    x = _bf(_t(rs.randn(n, cin, h, h)))
+    wt, b = _t(rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)), _t(rs.randn(cout))
+    temb, res = _t(rs.randn(n, cout)), _bf(_t(rs.randn(n, cout, h, h)))
+    ref = F.conv2d(x, _bf(wt), b, padding=1) + temb[:, :, None, None] + res
+    W, B, TE = torch.nn.Parameter(wt.to(DEV)), b.to(DEV), temb.to(DEV)
+    out = E.to_nchw(E.conv3x3(_act(x), W, B, rowbias=TE, ldrb=cout, residual=_act(res)))
+    _check(out, ref, 1.5e-3, 6e-4, "split-K conv")
+    one = E.to_nchw(E.conv3x3(_act(x[1:]), W, B, rowbias=TE[1:].contiguous(), ldrb=cout, residual=_act(res[1:])))
+    assert torch.equal(one, out[1:])
+    m, nn, k = 288, 1280, 2560
+    assert L.load().sdmi_gemm_ws_bytes(m, nn, k, 1, 144, 0) > 0
+    a, w2 = _bf(_t(rs.randn(m, k))), _bf(_t(rs.randn(nn, k) / np.sqrt(k)))
+    A = E.Act(a.to(H16).to(DEV).reshape(2, 144, k), 2, 12, 12, k)
+    o = E.gemm(A, w2.to(H16).to(DEV).contiguous(), nn)
+    _check(o.buf.reshape(m, nn), a @ w2.t(), 1.5e-3, 6e-4, "split-K gemm")
