@@ -9,16 +9,23 @@
 
 // ------------------------------------------------------------------------------------ GroupNorm
 __device__ __attribute__((aligned(16))) unsigned g_norm_zero16[4] = {0u, 0u, 0u, 0u};
-// pass 1a: per-block partial (sum, sumsq) of every group.  grid (nblk, N); a wave reads whole rows
-// (lane -> 8-channel chunk lane, lane+64, ...), keeps per-channel sums in registers, the 4 waves
-// combine through LDS in wave order, then thread g folds the channels of group g.
+
+// Lane mapping shared by the stats and apply kernels: a wave covers RPP = 64/LPR rows per pass, LPR = lanes per row
+// (64 when C/8 >= 64, else the next power of two >= C/8), lane -> (row sub-index lane/LPR, 16-byte chunk lane%LPR
+// [+64*s]).  A lane always owns the same channels, so per-channel state (sums, scale/shift) lives in registers.
+
+// pass 1a: per-block partial (sum, sumsq) of every group.  grid (nblk, N).  Per-channel sums in registers, rows
+// sub-indices folded by shuffles, the 4 waves combined through LDS in wave order, thread g folds group g: fixed
+// order everywhere (bit-reproducible).
 template <int NS>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const u16* __restrict__ x, int hw, int c, int ldx,
-                                                         int rows_per_block, int cpg, float* __restrict__ partial) {
+                                                         int rows_per_block, int cpg, int lpr_shift,
+                                                         float* __restrict__ partial) {
   __shared__ float s_sum[2560], s_sq[2560];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
   const int cc = c >> 3;
+  const int lpr = 1 << lpr_shift, rpp = 64 >> lpr_shift, rsub = lane >> lpr_shift, chl = lane & (lpr - 1);
   const int row_beg = blk * rows_per_block;
   const int row_end = min(hw, row_beg + rows_per_block);
   float a[NS][8], b[NS][8];
@@ -28,15 +35,15 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const u16* __restrict__
     for (int e = 0; e < 8; ++e) a[s][e] = b[s][e] = 0.f;
   const u16* base = x + (long long)n * hw * ldx;
   const u16* const zp = (const u16*)g_norm_zero16;
-  // 4 rows per wave in flight per iteration; rows past the block / chunks past C read a zero page (adds 0)
-  for (int row = row_beg + wv; row < row_end; row += 16) {
+  // 4 passes per wave in flight per iteration; rows past the block / chunks past C read a zero page (adds 0)
+  for (int row = row_beg + wv * rpp + rsub; row < row_end; row += 16 * rpp) {
     u32x4 v[4][NS];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int rr = row + 4 * j;
+      const int rr = row + 4 * rpp * j;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const int ch = lane + 64 * s;
+        const int ch = chl + 64 * s;
         v[j][s] = *(const u32x4*)((rr < row_end && ch < cc) ? base + (long long)rr * ldx + ch * 8 : zp);
       }
     }
@@ -50,11 +57,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const u16* __restrict__
         for (int e = 0; e < 8; ++e) { a[s][e] += f[e]; b[s][e] += f[e] * f[e]; }
       }
   }
+  // fold the row sub-indices (lanes chl, chl+LPR, ...) : butterfly over the high lane bits
+  for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[s][e] += __shfl_xor(a[s][e], o); b[s][e] += __shfl_xor(b[s][e], o); }
+  }
   for (int w = 0; w < 4; ++w) {
-    if (wv == w) {
+    if (wv == w && rsub == 0) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const int ch = lane + 64 * s;
+        const int ch = chl + 64 * s;
         if (ch < cc) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -90,9 +104,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     double s0 = 0.0, s1 = 0.0;
     if (gg < groups)
       for (int b = sub; b < nblk; b += 8) {
-        const float* pp = partial + (((long long)n * nblk + b) * groups + gg) * 2;
-        s0 += (double)pp[0];
-        s1 += (double)pp[1];
+        const float2 pp = *(const float2*)(partial + (((long long)n * nblk + b) * groups + gg) * 2);
+        s0 += (double)pp.x;
+        s1 += (double)pp.y;
       }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
@@ -117,33 +131,76 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
-// pass 2: y = act(x*scale + shift).  one thread per 8-channel chunk, grid-stride.
+// pass 2: y = act(x*scale + shift).  grid (nblk, N); same lane mapping; the lane's scale/shift stay in registers
+// for all its rows, two passes per wave in flight.
+template <int NS>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x, int ldx, const float* __restrict__ ss,
-                                                       u16* __restrict__ y, int ldy, int hw, int c, long long total,
-                                                       int silu) {
+                                                       u16* __restrict__ y, int ldy, int hw, int c, int rows_per_block,
+                                                       int lpr_shift, int silu) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int n = blockIdx.y;
   const int cc = c >> 3;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const long long row = idx / cc;
-    const int ch = (int)(idx - row * cc);
-    const int n = (int)(row / hw);
-    float f[8];
-    unpack8(*(const uint4*)(x + row * ldx + ch * 8), f);
-    const float4* sp = (const float4*)(ss + ((long long)n * c + ch * 8) * 2);
+  const int lpr = 1 << lpr_shift, rpp = 64 >> lpr_shift, rsub = lane >> lpr_shift, chl = lane & (lpr - 1);
+  const int row_beg = blockIdx.x * rows_per_block;
+  const int row_end = min(hw, row_beg + rows_per_block);
+  float sc[NS][8], sh[NS][8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float4 v = sp[e];
-      float a0 = f[2 * e] * v.x + v.y, a1 = f[2 * e + 1] * v.z + v.w;
-      if (silu) { a0 = silu_f(a0); a1 = silu_f(a1); }
-      f[2 * e] = a0;
-      f[2 * e + 1] = a1;
+  for (int s = 0; s < NS; ++s) {
+    const int ch = chl + 64 * s;
+    if (ch < cc) {
+      const float4* sp = (const float4*)(ss + ((long long)n * c + ch * 8) * 2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 v = sp[e];
+        sc[s][2 * e] = v.x; sh[s][2 * e] = v.y; sc[s][2 * e + 1] = v.z; sh[s][2 * e + 1] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[s][e] = 0.f; sh[s][e] = 0.f; }
     }
-    *(uint4*)(y + row * ldy + ch * 8) = pack8(f);
+  }
+  const u16* xb = x + (long long)n * hw * ldx;
+  u16* yb = y + (long long)n * hw * ldy;
+  const u16* const zp = (const u16*)g_norm_zero16;
+  for (int row = row_beg + wv * rpp + rsub; row < row_end; row += 8 * rpp) {
+    u32x4 v[2][NS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = row + 4 * rpp * j;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int ch = chl + 64 * s;
+        v[j][s] = *(const u32x4*)((rr < row_end && ch < cc) ? xb + (long long)rr * ldx + ch * 8 : zp);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = row + 4 * rpp * j;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int ch = chl + 64 * s;
+        float f[8];
+        unpack8(make_uint4(v[j][s][0], v[j][s][1], v[j][s][2], v[j][s][3]), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float o = f[e] * sc[s][e] + sh[s][e];
+          f[e] = silu ? silu_f(o) : o;
+        }
+        if (rr < row_end && ch < cc) *(uint4*)(yb + (long long)rr * ldy + ch * 8) = pack8(f);
+      }
+    }
   }
 }
 
 static int gn_nblk(int hw) {
   int nb = (hw + 31) / 32;
   return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+}
+static int gn_lpr_shift(int c) {
+  const int cc = c / 8;
+  int sh = 0;
+  while ((1 << sh) < cc && sh < 6) ++sh;
+  return sh;
 }
 
 extern "C" int64_t sdmi_groupnorm_ws_bytes(int n, int hw, int c) {
@@ -156,21 +213,22 @@ extern "C" int sdmi_groupnorm_stats(const void* x, int n, int hw, int c, int ldx
   SDMI_REQUIRE(x && gamma && beta && scale_shift && ws, "groupnorm_stats: null pointer");
   SDMI_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldx >= c, "groupnorm_stats: c and ldx must be multiples of 8 (c=%d ldx=%d)", c, ldx);
   SDMI_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "groupnorm_stats: groups=%d does not divide c=%d", groups, c);
-  SDMI_REQUIRE(c <= 2560, "groupnorm_stats: c=%d > 2560", c);
-  SDMI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)scale_shift & 15) == 0, "groupnorm_stats: alignment");
+  SDMI_REQUIRE(c <= 2560 && n <= 65535, "groupnorm_stats: c=%d > 2560 or n too large", c);
+  SDMI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)scale_shift & 15) == 0 && ((uintptr_t)ws & 7) == 0, "groupnorm_stats: alignment");
   hipStream_t st = (hipStream_t)stream;
   const int nblk = gn_nblk(hw);
   const int rpb = (hw + nblk - 1) / nblk;
   const int ns = (c / 8 + 63) / 64;
+  const int lsh = gn_lpr_shift(c);
   dim3 grid(nblk, n), block(256);
   const u16* xp = (const u16*)x;
   float* part = (float*)ws;
   switch (ns) {
-    case 1: hipLaunchKernelGGL(gn_partial_kernel<1>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
-    case 2: hipLaunchKernelGGL(gn_partial_kernel<2>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
-    case 3: hipLaunchKernelGGL(gn_partial_kernel<3>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
-    case 4: hipLaunchKernelGGL(gn_partial_kernel<4>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
-    default: hipLaunchKernelGGL(gn_partial_kernel<5>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, part); break;
+    case 1: hipLaunchKernelGGL(gn_partial_kernel<1>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
+    case 2: hipLaunchKernelGGL(gn_partial_kernel<2>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
+    case 3: hipLaunchKernelGGL(gn_partial_kernel<3>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
+    case 4: hipLaunchKernelGGL(gn_partial_kernel<4>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
+    default: hipLaunchKernelGGL(gn_partial_kernel<5>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
   }
   int rc = sdmi_check_launch("groupnorm partial");
   if (rc) return rc;
@@ -182,12 +240,26 @@ extern "C" int sdmi_groupnorm_apply(const void* x, int ldx, const float* scale_s
                                     int c, uint32_t flags, void* stream) {
   SDMI_REQUIRE(x && scale_shift && y, "groupnorm_apply: null pointer");
   SDMI_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c, "groupnorm_apply: c/ldx/ldy must be multiples of 8");
+  SDMI_REQUIRE(c <= 2560 && n <= 65535, "groupnorm_apply: c=%d > 2560 or n too large", c);
   SDMI_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)scale_shift) & 15) == 0, "groupnorm_apply: alignment");
-  const long long total = (long long)n * hw * (c / 8);
-  long long nb = (total + 255) / 256;
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const u16*)x, ldx, scale_shift,
-                     (u16*)y, ldy, hw, c, total, (flags & SDMI_F_SILU) ? 1 : 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int lsh = gn_lpr_shift(c);
+  const int rpp = 64 >> lsh;
+  // >= 8 passes per wave (32*rpp rows per block), at most ~2048 blocks per sample
+  int rpb = 32 * rpp;
+  if ((hw + rpb - 1) / rpb > 2048) rpb = (hw + 2047) / 2048;
+  dim3 grid((hw + rpb - 1) / rpb, n), block(256);
+  const int ns = (c / 8 + 63) / 64;
+  const int silu = (flags & SDMI_F_SILU) ? 1 : 0;
+  const u16* xp = (const u16*)x;
+  u16* yp = (u16*)y;
+  switch (ns) {
+    case 1: hipLaunchKernelGGL(gn_apply_kernel<1>, grid, block, 0, st, xp, ldx, scale_shift, yp, ldy, hw, c, rpb, lsh, silu); break;
+    case 2: hipLaunchKernelGGL(gn_apply_kernel<2>, grid, block, 0, st, xp, ldx, scale_shift, yp, ldy, hw, c, rpb, lsh, silu); break;
+    case 3: hipLaunchKernelGGL(gn_apply_kernel<3>, grid, block, 0, st, xp, ldx, scale_shift, yp, ldy, hw, c, rpb, lsh, silu); break;
+    case 4: hipLaunchKernelGGL(gn_apply_kernel<4>, grid, block, 0, st, xp, ldx, scale_shift, yp, ldy, hw, c, rpb, lsh, silu); break;
+    default: hipLaunchKernelGGL(gn_apply_kernel<5>, grid, block, 0, st, xp, ldx, scale_shift, yp, ldy, hw, c, rpb, lsh, silu); break;
+  }
   return sdmi_check_launch("groupnorm apply");
 }
 
