@@ -18,7 +18,7 @@ struct AttnParams {
   const u16* q; const u16* k; const u16* v; u16* o;
   long long sq, sk, sv, so;
   int ldq, ldk, ldv, ldo;
-  int nq, nkv;
+  int nq, nkv, nqt, heads;
   float scale_log2;
 };
 
@@ -27,17 +27,89 @@ __device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4] = {0u, 0u, 0u,
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 1) << 2)) << 3); }
 
+// One KV tile for one wave: S^T = K Q^T, online softmax with the query on the lane, O^T += V^T P^T.
+__device__ __forceinline__ void attn_tile(bool tail, const u16* sK, const u16* sV, const hx8 (&qf)[4], f32x16 (&oacc)[2], float& mrun,
+                                          float& lrun, float scale_log2, int kv0, int nkv, int r, int hh, int dblk, int tq,
+                                          int tp) {
+  f32x16 s[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+#pragma unroll
+  for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const hx8 a = *(const hx8*)&sK[k_off(32 * kt2 + r, 2 * ks + hh)];
+      s[kt2] = MFMA32(a, qf[ks], s[kt2], 0, 0, 0);
+    }
+  // raw-score max (scale > 0, so max commutes with the scaling); padded keys of the last tile are excluded
+  if (__builtin_amdgcn_readfirstlane((int)tail)) {  // wave-uniform: only the last, partial tile pays for the masking
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kv0 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (key >= nkv) s[kt2][i] = -1e30f;
+      }
+  }
+  float mx = -1e30f;
+#pragma unroll
+  for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kt2][i]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float mnew = fmaxf(mrun, mx * scale_log2);
+  const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+  mrun = mnew;
+  float rs = 0.f;
+#pragma unroll
+  for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt2][i], scale_log2, -mnew));
+      s[kt2][i] = e;
+      rs += e;
+    }
+  lrun = lrun * alpha + rs;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+#pragma unroll
+  for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      hx8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = (h16)s[kt2][8 * s2 + j];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int c = 4 * dt + 2 * dblk + (tp >> 1);
+        const int row0 = 32 * kt2 + 16 * s2 + 4 * hh + tq;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0, c) + 4 * (tp & 1)));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0 + 8, c) + 4 * (tp & 1)));
+        union { struct { short4_t a, b; } h; hx8 v; } u;
+        u.h.a = lo;
+        u.h.b = hi;
+        oacc[dt] = MFMA32(u.v, pb, oacc[dt], 0, 0, 0);
+      }
+    }
+}
+
+// grid: 1-D, nqt * heads * batch blocks; the XCD remap gives each XCD a contiguous run of (batch, head, q-tile) so
+// the K/V of the (one or two) heads an XCD is working on stay in its 4 MB L2 instead of being re-streamed by 8 XCDs.
 __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) u16 sK[64 * 64];
   __shared__ __attribute__((aligned(16))) u16 sV[64 * 64];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, bz = blockIdx.z;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = bid % p.nqt, bh = bid / p.nqt;
+  const int head = bh % p.heads, bz = bh / p.heads;
   const u16* Q = p.q + (long long)bz * p.sq + head * 64;
   const u16* K = p.k + (long long)bz * p.sk + head * 64;
   const u16* V = p.v + (long long)bz * p.sv + head * 64;
   u16* O = p.o + (long long)bz * p.so + head * 64;
 
-  const int qrow = blockIdx.x * 128 + wv * 32 + r;
+  const int qrow = qt * 128 + wv * 32 + r;
   const int qrc = qrow < p.nq ? qrow : p.nq - 1;
   hx8 qf[4];
 #pragma unroll
@@ -80,74 +152,11 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
     ATTN_STORE_TILE();
     __syncthreads();
     if (tile + 1 < ntiles) ATTN_LOAD_TILE(kv0 + 64);
-
-    // ---- S^T[key][q] ----
-    f32x16 s[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const hx8 a = *(const hx8*)&sK[k_off(32 * kt2 + r, 2 * ks + hh)];
-        s[kt2] = MFMA32(a, qf[ks], s[kt2], 0, 0, 0);
-      }
-    // ---- online softmax, query on the lane ----
-    const bool tail = kv0 + 64 > p.nkv;
-    float mx = -1e30f;
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float v = s[kt2][i] * p.scale_log2;
-        if (tail) {
-          const int key = kv0 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (key >= p.nkv) v = -1e30f;
-        }
-        s[kt2][i] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mnew = fmaxf(mrun, mx);
-    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-    mrun = mnew;
-    float rs = 0.f;
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(s[kt2][i] - mnew);
-        s[kt2][i] = e;
-        rs += e;
-      }
-    lrun = lrun * alpha + rs;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-
-    // ---- O^T[d][q] += V^T[d][key] P^T[key][q] ----
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        hx8 pb;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pb[j] = (h16)s[kt2][8 * s2 + j];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const int c = 4 * dt + 2 * dblk + (tp >> 1);
-          const int row0 = 32 * kt2 + 16 * s2 + 4 * hh + tq;
-          const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0, c) + 4 * (tp & 1)));
-          const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0 + 8, c) + 4 * (tp & 1)));
-          union { struct { short4_t a, b; } h; hx8 v; } u;
-          u.h.a = lo;
-          u.h.b = hi;
-          oacc[dt] = MFMA32(u.v, pb, oacc[dt], 0, 0, 0);
-        }
-      }
+    attn_tile(kv0 + 64 > p.nkv, sK, sV, qf, oacc, mrun, lrun, p.scale_log2, kv0, p.nkv, r, hh, dblk, tq, tp);
     __syncthreads();
   }
+#undef ATTN_LOAD_TILE
+#undef ATTN_STORE_TILE
 
   const float ltot = lrun + __shfl_xor(lrun, 32);
   const float inv = 1.0f / ltot;
@@ -173,12 +182,14 @@ extern "C" int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k,
   SDMI_REQUIRE(ldq >= heads * 64 && ldk >= heads * 64 && ldv >= heads * 64 && ldo >= heads * 64, "attention: row stride < heads*64");
   SDMI_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)o & 7) == 0, "attention: pointer alignment");
   SDMI_REQUIRE(sq % 8 == 0 && sk % 8 == 0 && sv % 8 == 0 && so % 4 == 0, "attention: batch strides must keep alignment");
-  SDMI_REQUIRE(heads <= 65535 && batch <= 65535, "attention: grid too large");
+  SDMI_REQUIRE(scale > 0.f, "attention: scale must be positive");
+  SDMI_REQUIRE((long long)((nq + 127) / 128) * heads * batch < (1ll << 31), "attention: grid too large");
   AttnParams p;
   p.q = (const u16*)q; p.k = (const u16*)k; p.v = (const u16*)v; p.o = (u16*)o;
   p.sq = sq; p.sk = sk; p.sv = sv; p.so = so; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.nq = nq; p.nkv = nkv; p.scale_log2 = scale * 1.44269504088896340736f;
-  dim3 grid((nq + 127) / 128, heads, batch), block(256);
+  p.nqt = (nq + 127) / 128; p.heads = heads;
+  dim3 grid(p.nqt * heads * batch), block(256);
   hipLaunchKernelGGL(attn64_kernel, grid, block, 0, (hipStream_t)stream, p);
   return sdmi_check_launch("attention");
 }

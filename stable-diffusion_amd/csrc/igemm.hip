@@ -291,7 +291,7 @@ static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags) {
   const long long tiles = (long long)((rows_per_sample + bm - 1) / bm) * ((n + bn - 1) / bn);
   if (tiles > 128) return 1;
   long long s = target / tiles;
-  if (s > nk / 8) s = nk / 8;
+  if (s > nk / 16) s = nk / 16;  // at least 1024 of K per split: below that the fp32 round trip costs more than it buys
   if (s > 16) s = 16;
   return s < 2 ? 1 : (int)s;
 }

@@ -245,9 +245,10 @@ extern "C" int sdmi_groupnorm_apply(const void* x, int ldx, const float* scale_s
   hipStream_t st = (hipStream_t)stream;
   const int lsh = gn_lpr_shift(c);
   const int rpp = 64 >> lsh;
-  // >= 8 passes per wave (32*rpp rows per block), at most ~2048 blocks per sample
-  int rpb = 32 * rpp;
-  if ((hw + rpb - 1) / rpb > 2048) rpb = (hw + 2047) / 2048;
+  // 2 passes per wave, both in flight (8*rpp rows per block): many small blocks keep enough bytes in flight per CU;
+  // very large tensors get longer blocks (<= 8192 per sample)
+  int rpb = 8 * rpp;
+  if ((hw + rpb - 1) / rpb > 8192) rpb = ((hw + 8191) / 8192 + 8 * rpp - 1) / (8 * rpp) * (8 * rpp);
   dim3 grid((hw + rpb - 1) / rpb, n), block(256);
   const int ns = (c / 8 + 63) / 64;
   const int silu = (flags & SDMI_F_SILU) ? 1 : 0;
