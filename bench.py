@@ -38,14 +38,15 @@ DECODE_GFLOP = {64: 2514.5, 96: 5754.3, 128: 10470.4}
 
 
 def work_of(name, a):
-    """(algorithmic flops, algorithmic bytes) of one C-ABI call from its arguments (see include/sdmi.h)."""
-    if name == "sdmi_conv3x3":
+    """(algorithmic flops, algorithmic bytes) of one C-ABI call from its arguments (see include/sdmi.h).  `name` is the
+    kernel symbol for conv/gemm/attention calls (sdmi_last_kernel), the entry point otherwise."""
+    if name.startswith("igemm_kernel") and "true>" in name:
         n, cin, cout, ho, wo = a[2], a[5], a[7], a[8], a[9]
         return 2.0 * n * ho * wo * cout * 9 * cin, 2.0 * (n * a[3] * a[4] * cin + n * ho * wo * cout + 9 * cin * cout)
-    if name == "sdmi_gemm":
+    if name.startswith("igemm_kernel"):
         m, n, k, b = a[9], a[10], a[11], a[12]
         return 2.0 * m * n * k * b, 2.0 * b * (m * k + n * k + m * n)
-    if name == "sdmi_attention":
+    if name == "attn64_kernel":
         b, h, nq, nk = a[12], a[13], a[14], a[15]
         return 4.0 * b * h * nq * nk * 64, 2.0 * b * h * 64 * (2 * nq + 2 * nk)
     if name == "sdmi_groupnorm_stats":

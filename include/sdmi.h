@@ -39,6 +39,9 @@ int sdmi_version(void);
 /* 16-bit storage type ("h16") of activations and packed weights this build uses: 0 = IEEE fp16 (default), 1 = bf16 */
 int sdmi_act_dtype(void);
 const char* sdmi_last_error(void);
+/* name of the kernel variant the last sdmi_conv3x3 / sdmi_gemm call on this thread launched (tile shape is chosen per
+ * problem), e.g. "igemm_kernel<128, 128, true>": lets a profiler key its numbers on the symbol rocprofv3 reports */
+const char* sdmi_last_kernel(void);
 
 /* ---- weight pre-pack (run once per parameter, after load_state_dict) ---------------------- */
 /* fp32 OIHW (Cout,Cin,3,3) -> bf16 [Cout][9][Cin].  replaces nothing: layout change for sdmi_conv3x3. */

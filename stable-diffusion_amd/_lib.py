@@ -19,6 +19,7 @@ PROTOTYPES = {
     "sdmi_version": (_i, []),
     "sdmi_act_dtype": (_i, []),
     "sdmi_last_error": (C.c_char_p, []),
+    "sdmi_last_kernel": (C.c_char_p, []),
     "sdmi_pack_conv3x3": (_i, [_vp, _vp, _i, _i, _vp]),
     "sdmi_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sdmi_nchw_f32_to_nhwc_h16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -105,6 +106,10 @@ def call(name, *args):
         e0.record(st)
         rc = getattr(lib, name)(*args)
         e1.record(st)
+        if name in ("sdmi_conv3x3", "sdmi_gemm"):
+            name = lib.sdmi_last_kernel().decode() or name
+        elif name == "sdmi_attention":
+            name = "attn64_kernel"
         TIMER.records.append((name, TIMER.work_fn(name, args), e0, e1))
     else:
         rc = getattr(lib, name)(*args)

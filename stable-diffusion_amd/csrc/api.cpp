@@ -22,6 +22,15 @@ int sdmi_check_launch(const char* what) {
   return SDMI_OK;
 }
 
+static thread_local char g_kernel[160] = "";
+void sdmi_note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* sdmi_last_kernel(void) { return g_kernel; }
+
 extern "C" int sdmi_version(void) { return 101; }
 #ifdef SDMI_BF16
 extern "C" int sdmi_act_dtype(void) { return 1; }

@@ -29,6 +29,7 @@ typedef h16 hx2 __attribute__((ext_vector_type(2)));
 // host side: error reporting (defined in api.cpp)
 void sdmi_set_error(const char* fmt, ...);
 int sdmi_check_launch(const char* what);
+void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the last entry point launched
 
 #define SDMI_REQUIRE(cond, ...)            \
   do {                                     \

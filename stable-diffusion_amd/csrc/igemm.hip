@@ -5,12 +5,11 @@
 // Replaces nn.Conv2d(k=3) / nn.Linear / nn.Conv2d(k=1) / F.interpolate / F.pad / GEGLU of the reference
 // (layers/ResBlock.py:17-19,:36-37,:67-76; layers/SpatialTransformer.py:22-26,:62-66,:110-129,:199,:204).
 //
-// Structure (gfx950): 256 threads = 4 waves in a 2x2 grid over a BM x BN tile, BK = 64.  Both operands
-// are K-contiguous, staged global -> registers -> LDS (16 B per lane, XOR-swizzled 128-B rows so the
-// ds_read_b128 fragment reads are bank-conflict free), double-buffered: the global loads of tile k+1 are
-// issued before the MFMAs of tile k and written to the other LDS buffer after them (one barrier per
-// K-tile).  v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand, so a lane ends up with 4
-// consecutive output channels of one pixel (8-byte bf16 stores, 16-byte fp32 bias loads).
+// Structure (gfx950): 256 threads = 4 waves in a 2x2 grid over a BM x BN tile, BK = 64.  Both operands are
+// K-contiguous and staged by LDS-DMA (global_load_lds_dwordx4, 16 B per lane) into a linear LDS image whose XOR
+// swizzle (conflict-free ds_read_b128 fragment reads) is applied on the source address; two LDS buffers, the DMA of
+// tile k+1 is in flight over the MFMAs of tile k, one barrier per K-tile.  v_mfma_f32_16x16x32_f16 with the WEIGHT
+// fragment as the A operand, so a lane ends up with 4 consecutive output channels of one pixel (8-byte stores).
 #include <stdlib.h>
 #include "common.h"
 
@@ -112,24 +111,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const u16* Wp = p.w + (long long)bz * p.sw;
   const int chunk = t & 7, r0 = t >> 3;
 
-  // ---- per-thread row bookkeeping (fixed over the K loop) ----
-  bool a_ok[PA];
+  // Staging is LDS-DMA (global_load_lds_dwordx4): each wave-instruction moves 64 x 16 B = 8 tile rows straight into
+  // LDS, no VGPR round trip and no ds_write (which costs ~3x a read per byte on gfx950).  The LDS image is linear in
+  // lane order, so the XOR swizzle is applied on the SOURCE side: the lane that fills physical chunk (t&7) of its row
+  // fetches logical chunk (t&7)^f(row).  Out-of-range rows / taps / k-chunks fetch 16 zero bytes from g_zero16, so
+  // every load is unconditional.  __syncthreads() drains the DMA (vmcnt) before the tile is read.
+  const u16* const zp = (const u16*)g_zero16;
+  const int lchunk = chunk ^ ((r0 >> 1) & 7);  // logical chunk this lane fetches
+  const int wave_row0 = __builtin_amdgcn_readfirstlane(wv) * 8;
+
+  // ---- per-thread row bookkeeping, fixed over the K loop.  Everything that depends only on the row is hoisted here:
+  // for a conv, the row pointer already includes the output pixel's position and this lane's chunk, and a 9-bit mask
+  // says which taps fall inside the image, so a K-tile costs one test, one uniform offset add and one select per row.
   const u16* a_ptr[PA];
-  int a_oy[PA], a_ox[PA];
+  int a_mask[PA];                 // CONV: bit t set = tap t readable; GEMM: 1 = row valid
+  int a_oy[PA], a_ox[PA];         // CONV with upsample only
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int gm = brow + r0 + 32 * i;
-    a_ok[i] = gm < p.M;
-    const int gmc = a_ok[i] ? gm : 0;
+    const bool ok = gm < p.M;
+    const int gmc = ok ? gm : 0;
     if constexpr (CONV) {
       const int hw = p.Ho * p.Wo;
       const int img = gmc / hw, rem = gmc - img * hw;
-      a_oy[i] = rem / p.Wo;
-      a_ox[i] = rem - a_oy[i] * p.Wo;
-      a_ptr[i] = A + (long long)img * p.H * p.W * p.lda;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+      int mask = 0;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int iy = oy * p.stride + tp / 3 - p.pad_t, ix = ox * p.stride + tp % 3 - p.pad_l;
+        if (ok && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim) mask |= 1 << tp;
+      }
+      a_mask[i] = mask;
+      a_oy[i] = oy;
+      a_ox[i] = ox;
+      const u16* base = A + (long long)img * p.H * p.W * p.lda + lchunk * 8;
+      // no upsample: pointer to tap (0,0) of this output pixel (may lie outside the image: only dereferenced when the
+      // tap's mask bit is set); the tap then adds the uniform offset (ky*W + kx)*lda
+      a_ptr[i] = p.ups ? base : base + ((long long)(oy * p.stride - p.pad_t) * p.W + (ox * p.stride - p.pad_l)) * p.lda;
     } else {
+      a_mask[i] = ok ? 1 : 0;
       a_oy[i] = a_ox[i] = 0;
-      a_ptr[i] = A + (long long)gmc * p.lda;
+      a_ptr[i] = A + (long long)gmc * p.lda + lchunk * 8;
     }
   }
   bool b_ok[PB];
@@ -138,56 +161,58 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   for (int i = 0; i < PB; ++i) {
     const int gn = bcol + r0 + 32 * i;
     b_ok[i] = gn < p.N;
-    b_ptr[i] = Wp + (long long)(b_ok[i] ? gn : 0) * p.ldw;
+    b_ptr[i] = Wp + (long long)(b_ok[i] ? gn : 0) * p.ldw + lchunk * 8;
   }
+  const int k_lim = (CONV ? p.Cin : p.K) - lchunk * 8;  // this lane's chunk is inside K iff (uniform k offset) < k_lim
 
-  // Out-of-range rows / taps / k-chunks read 16 zero bytes from g_zero16 instead of being predicated: every
-  // global load is unconditional, so the loads of tile k+1 stay in flight across the MFMAs of tile k (a
-  // predicated load makes hipcc wait for it inside its own branch).
-  u32x4 ra[PA], rb[PB];
-  const u16* const zp = (const u16*)g_zero16;
   const int kt_begin = blockIdx.z * p.kt_per_split;
   const int kt_end = min(p.nk, kt_begin + p.kt_per_split);
   int tap = kt_begin / p.kt_per_tap, cb = kt_begin - tap * p.kt_per_tap;  // CONV: position of the NEXT tile to load
 
-#define IGEMM_LOAD_TILE(KT)                                                                                       \
+#define IGEMM_GLDS(SRC, DST) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+#define IGEMM_STAGE_TILE(KT, BUF)                                                                                 \
   {                                                                                                               \
+    u16* dA = sA + (BUF) * BM * 64 + wave_row0 * 64;                                                              \
+    u16* dB = sB + (BUF) * BN * 64 + wave_row0 * 64;                                                              \
     if constexpr (CONV) {                                                                                         \
       const int ky = tap / 3, kx = tap - 3 * ky;                                                                  \
-      const int c = cb * 64 + chunk * 8;                                                                          \
-      const bool cok = c < p.Cin;                                                                                 \
-      const int hlim = p.H << p.ups, wlim = p.W << p.ups;                                                         \
-      _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                            \
-        int iy = a_oy[i] * p.stride + ky - p.pad_t, ix = a_ox[i] * p.stride + kx - p.pad_l;                       \
-        const bool ok = a_ok[i] && cok && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;                           \
-        iy >>= p.ups;                                                                                             \
-        ix >>= p.ups;                                                                                             \
-        const u16* src = ok ? a_ptr[i] + ((long long)(iy * p.W + ix) * p.lda + c) : zp;                           \
-        ra[i] = *(const u32x4*)src;                                                                               \
+      const int c0 = cb * 64;                                                                                     \
+      const bool cok = c0 < k_lim;                                                                                \
+      const int tbit = 1 << tap;                                                                                  \
+      if (p.ups) {                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                          \
+          const int iy = (a_oy[i] + ky - p.pad_t) >> 1, ix = (a_ox[i] + kx - p.pad_l) >> 1;                       \
+          const bool ok = (a_mask[i] & tbit) && cok;                                                              \
+          const u16* src = ok ? a_ptr[i] + ((long long)(iy * p.W + ix) * p.lda + c0) : zp;                        \
+          IGEMM_GLDS(src, dA + i * 32 * 64);                                                                      \
+        }                                                                                                         \
+      } else {                                                                                                    \
+        const long long toff = (long long)(ky * p.W + kx) * p.lda + c0;                                           \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                          \
+          const bool ok = (a_mask[i] & tbit) && cok;                                                              \
+          const u16* src = ok ? a_ptr[i] + toff : zp;                                                             \
+          IGEMM_GLDS(src, dA + i * 32 * 64);                                                                      \
+        }                                                                                                         \
       }                                                                                                           \
-      const int wk = tap * p.Cin + c;                                                                             \
+      const int wk = tap * p.Cin + c0;                                                                            \
       _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                            \
         const u16* src = (b_ok[i] && cok) ? b_ptr[i] + wk : zp;                                                   \
-        rb[i] = *(const u32x4*)src;                                                                               \
+        IGEMM_GLDS(src, dB + i * 32 * 64);                                                                        \
       }                                                                                                           \
       if (++cb == p.kt_per_tap) { cb = 0; ++tap; }                                                                \
     } else {                                                                                                      \
-      const int ko = (KT) * 64 + chunk * 8;                                                                       \
-      const bool kok = ko < p.K;                                                                                  \
+      const int ko = (KT) * 64;                                                                                   \
+      const bool kok = ko < k_lim;                                                                                \
       _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                            \
-        const u16* src = (a_ok[i] && kok) ? a_ptr[i] + ko : zp;                                                   \
-        ra[i] = *(const u32x4*)src;                                                                               \
+        const u16* src = (a_mask[i] && kok) ? a_ptr[i] + ko : zp;                                                 \
+        IGEMM_GLDS(src, dA + i * 32 * 64);                                                                        \
       }                                                                                                           \
       _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                            \
         const u16* src = (b_ok[i] && kok) ? b_ptr[i] + ko : zp;                                                   \
-        rb[i] = *(const u32x4*)src;                                                                               \
+        IGEMM_GLDS(src, dB + i * 32 * 64);                                                                        \
       }                                                                                                           \
     }                                                                                                             \
-  }
-#define IGEMM_STORE_TILE(BUF)                                                                                     \
-  {                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < PA; ++i) *(u32x4*)&sA[(BUF) * BM * 64 + lds_off(r0 + 32 * i, chunk)] = ra[i]; \
-    _Pragma("unroll") for (int i = 0; i < PB; ++i) *(u32x4*)&sB[(BUF) * BN * 64 + lds_off(r0 + 32 * i, chunk)] = rb[i]; \
   }
 
   f32x4 acc[MT][NT];
@@ -196,13 +221,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  IGEMM_LOAD_TILE(kt_begin);
-  IGEMM_STORE_TILE(0);
+  IGEMM_STAGE_TILE(kt_begin, 0);
   __syncthreads();
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = kt + 1 < kt_end;
-    if (more) IGEMM_LOAD_TILE(kt + 1);
+    if (more) IGEMM_STAGE_TILE(kt + 1, cur ^ 1);
     const u16* cA = sA + cur * BM * 64;
     const u16* cB = sB + cur * BN * 64;
 #pragma unroll
@@ -218,12 +242,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    if (more) IGEMM_STORE_TILE(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
-#undef IGEMM_LOAD_TILE
-#undef IGEMM_STORE_TILE
+#undef IGEMM_STAGE_TILE
+#undef IGEMM_GLDS
 
   // ---- epilogue: lane holds out[m][n0..n0+3], m = tile row l15, n0 = 4*lq within each 16x16 tile ----
   const uint32_t fl = p.flags;
@@ -329,6 +352,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   else if (bm128) hipLaunchKernelGGL((igemm_kernel<128, 64, CONV>), grid, block, 0, st, p);
   else if (bn128) hipLaunchKernelGGL((igemm_kernel<64, 128, CONV>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((igemm_kernel<64, 64, CONV>), grid, block, 0, st, p);
+  sdmi_note_kernel("igemm_kernel<%d, %d, %s>%s", bm, bn, CONV ? "true" : "false", p.splits > 1 ? " + igemm_splitk_reduce_kernel" : "");
   int rc = sdmi_check_launch(CONV ? "conv3x3" : "gemm");
   if (rc || p.splits < 2) return rc;
   long long items = (long long)batch * p.M * (p.npad / 4);
