@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from layers.ResBlock import ResBlock, Downsample, Upsample
-from layers.SpatialTransformer import SpatialTransformer
+from layers.SpatialTransformer import SpatialTransformer, ContextKV
 from stable_diffusion_amd import engine as E
 
 
@@ -68,6 +68,21 @@ class Unet(nn.Module):
                     if isinstance(m, ResBlock):
                         yield m
 
+    def _cross_attn_modules(self):
+        for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
+            if isinstance(blk, nn.ModuleList):
+                for m in blk:
+                    if isinstance(m, SpatialTransformer):
+                        yield m.transformer_blocks[0].attn2
+
+    @torch.no_grad()
+    def precompute_context(self, context):
+        """Project the (2b, 77, 1024) text context through every cross-attention to_k / to_v once.  The result can be
+        passed as `context=` to forward() for every DDIM step of the same prompt (step-invariant hoisting)."""
+        if isinstance(context, list):
+            context = context[0]
+        return ContextKV(list(self._cross_attn_modules()), context)
+
     def _embeddings(self, timesteps):
         """t_emb MLP (Unet.py:112-114) + every ResBlock's emb_proj(SiLU(t_emb)) (layers/ResBlock.py:70), batched."""
         t = E.timestep_embedding(timesteps, self.emb_channels)
@@ -106,7 +121,7 @@ class Unet(nn.Module):
         n, _, hh, ww = x.shape
         dev = x.device
         keep, emb, ldrb = self._embeddings(timesteps)
-        ctx = E.tokens_from_f32(context)
+        ctx = context if isinstance(context, ContextKV) else self.precompute_context(context)
 
         # ---- geometry + concat plan: skip k is consumed by output block (K-1-k) next to an `h` of cat_c1[k] channels
         nin = len(self.input_blocks)

@@ -14,8 +14,25 @@ def zero_module(module):
     return module
 
 
+class ContextKV(object):
+    """Pre-projected text context: the to_k|to_v outputs of every cross-attention layer, computed by ONE stacked GEMM
+    (they depend only on the prompt, not on the latent or the timestep: 32 Linears per UNet step in the reference,
+    layers/SpatialTransformer.py:73-74).  `kv[id(attn_module)]` is that layer's (B, 77, 2*inner) view."""
+
+    def __init__(self, attn_modules, context):
+        ctx = context if isinstance(context, E.Act) else E.tokens_from_f32(context)
+        ws = tuple(w for m in attn_modules for w in (m.to_k.weight, m.to_v.weight))
+        ntot = sum(w.shape[0] for w in ws)
+        allkv = E.gemm(ctx, E.packed_linear(ws), ntot)
+        self.kv, off = {}, 0
+        for m in attn_modules:
+            n2 = m.to_k.weight.shape[0] + m.to_v.weight.shape[0]
+            self.kv[id(m)] = allkv.cols(off, n2)
+            off += n2
+
+
 def _as_ctx(context):
-    if context is None or isinstance(context, E.Act):
+    if context is None or isinstance(context, (E.Act, ContextKV)):
         return context
     return E.tokens_from_f32(context)
 
@@ -79,7 +96,10 @@ class MemoryEfficientCrossAttention(nn.Module):
             q, k, v = qkv.cols(0, inner), qkv.cols(inner, inner), qkv.cols(2 * inner, inner)
         else:
             q = E.gemm(a, E.packed_linear((self.to_q.weight,)), inner)
-            kv = E.gemm(context, E.packed_linear((self.to_k.weight, self.to_v.weight)), 2 * inner)
+            if isinstance(context, ContextKV):
+                kv = context.kv[id(self)]
+            else:
+                kv = E.gemm(context, E.packed_linear((self.to_k.weight, self.to_v.weight)), 2 * inner)
             k, v = kv.cols(0, inner), kv.cols(inner, inner)
         o = E.attention(q, k, v, self.heads)
         lin = self.to_out[0]

@@ -47,7 +47,7 @@ class Sampler(object):
     def _unet_step(self, xc, t_buf, cc, use_graph):
         if not use_graph:
             return self.unet(xc, timesteps=t_buf, context=cc)
-        key = (xc.data_ptr(), t_buf.data_ptr(), cc.data_ptr(), tuple(xc.shape))
+        key = (xc.data_ptr(), t_buf.data_ptr(), id(cc), tuple(xc.shape))
         if self._gkey != key:
             self.unet(xc, timesteps=t_buf, context=cc)          # warm-up: weight pre-pack, allocator pools
             torch.cuda.synchronize()
@@ -72,7 +72,8 @@ class Sampler(object):
         xc[b:, :4] = x_T
         xc[:b, 4:] = c_concat
         xc[b:, 4:] = c_concat
-        cc = torch.cat([uncond, cond]).contiguous()
+        # text-context K/V projections do not depend on the step: project once per prompt
+        cc = self.unet.precompute_context(torch.cat([uncond, cond]).contiguous())
         t_buf = torch.empty((2 * b,), dtype=torch.long, device=dev)
         x = x_T.clone()
         for i, step in enumerate(np.flip(ts)):
