@@ -107,7 +107,9 @@ def call(name, *args):
         rc = getattr(lib, name)(*args)
         e1.record(st)
         if name in ("sdmi_conv3x3", "sdmi_gemm"):
-            name = lib.sdmi_last_kernel().decode() or name
+            # kernel symbol as rocprofv3 reports it; a split-K launch is keyed on its main kernel (its fixed-order
+            # reduce kernel, a few us, rides inside the same event pair)
+            name = (lib.sdmi_last_kernel().decode() or name).split(" + ")[0]
         elif name == "sdmi_attention":
             name = "attn64_kernel"
         TIMER.records.append((name, TIMER.work_fn(name, args), e0, e1))

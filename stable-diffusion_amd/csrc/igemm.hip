@@ -381,7 +381,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   else if (bm128) hipLaunchKernelGGL((igemm_kernel<128, 64, CONV, 2>), grid, block, 0, st, p);
   else if (bn128) hipLaunchKernelGGL((igemm_kernel<64, 128, CONV, 3>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((igemm_kernel<64, 64, CONV, 3>), grid, block, 0, st, p);
-  sdmi_note_kernel("igemm_kernel<%d, %d, %s>%s", bm, bn, CONV ? "true" : "false", p.splits > 1 ? " + igemm_splitk_reduce_kernel" : "");
+  sdmi_note_kernel("igemm_kernel<%d, %d, %s, %d>%s", bm, bn, CONV ? "true" : "false", bm128 ? 2 : 3, p.splits > 1 ? " + igemm_splitk_reduce_kernel" : "");
   int rc = sdmi_check_launch(CONV ? "conv3x3" : "gemm");
   if (rc || p.splits < 2) return rc;
   long long items = (long long)batch * p.M * (p.npad / 4);
