@@ -29,6 +29,7 @@ struct IgemmParams {
   // split-K: grid.z splits of kt_per_split K-tiles each write fp32 partials [split][batch][M][npad] to ws
   int splits, kt_per_split, npad;
   float* ws;
+  int fast_epi;  // host-checked: shapes / alignments allow the LDS-transposed 16-byte epilogue
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};  // non-const: stays in the global address space (no flat loads)
@@ -98,6 +99,135 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
     }
     float y[4] = {a.x, a.y, a.z, a.w};
     epilogue4(p, bz, m, q * 4, y);
+  }
+}
+
+
+// ---- fast epilogue.  The MFMA layout leaves a lane with 4 channels of one row (8-byte pieces, a dependent bias /
+// residual load each).  Instead every wave transposes its accumulators through a private LDS strip, 16 rows at a time,
+// so that a lane owns 8 consecutive channels of a row: bias / per-sample bias / residual arrive as 16-byte loads that
+// are all issued up front (one wait), and the stores are 16 bytes per lane over whole 64- or 128-byte row segments.
+// Arithmetic order per element is that of epilogue4 (alpha, bias, per-sample bias, residual).
+template <int BM, int BN, bool GEGLU>
+__device__ __forceinline__ void epilogue_fast(const IgemmParams& p, float* wreg, f32x4 (&acc)[BM / 32][BN / 32], int bz,
+                                              int brow, int bcol, int wr, int wc, int lane) {
+  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int OW = GEGLU ? BN / 4 : BN / 2;  // output columns of this wave per row
+  constexpr int W = OW + 4;                    // padded strip row (floats)
+  constexpr int CH = OW / 8;                   // 8-channel chunks per row
+  constexpr int RPP = 64 / CH;                 // rows per pass
+  constexpr int PASSES = 16 / RPP;
+  static_assert(RPP <= 16, "strip is 16 rows");
+  const uint32_t fl = p.flags;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int rrow = lane / CH, c = lane % CH;
+  const int nout = GEGLU ? p.N >> 1 : p.N;
+  const int colbase = GEGLU ? (bcol + wc * (BN / 2)) >> 1 : bcol + wc * (BN / 2);
+  const bool cvalid = colbase + c * 8 < nout;
+  const int ocol = cvalid ? colbase + c * 8 : 0;
+  const int row0 = brow + wr * (BM / 2);
+  const int hwo = p.rows_per_sample;
+
+  // everything that comes from memory is requested first
+  f32x4 bia[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 gb[GEGLU ? NT : 1];  // GEGLU: value / gate bias in MFMA layout
+  f32x4 rb[2][2] = {{bia[0], bia[0]}, {bia[0], bia[0]}};
+  u32x4 rres[MT * PASSES];
+  int s_first = 0;
+  if constexpr (GEGLU) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) gb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (fl & SDMI_F_BIAS) {
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int nb0 = bcol + wc * (BN / 2) + j * 16;
+        const int oc = nb0 < p.N ? (nb0 >> 5) * 16 + lq * 4 : 0;
+        gb[j] = *(const f32x4*)(p.bias + oc);
+        gb[j + 1] = *(const f32x4*)(p.bias + nout + oc);
+      }
+    }
+  } else {
+    if (fl & SDMI_F_BIAS) {
+      bia[0] = *(const f32x4*)(p.bias + ocol);
+      bia[1] = *(const f32x4*)(p.bias + ocol + 4);
+    }
+    if (fl & SDMI_F_ROWBIAS) {  // host guarantees rows_per_sample >= BM: a tile touches at most two samples
+      s_first = row0 / hwo;
+      const int s_last = (p.M - 1) / hwo;
+      const float* r0 = p.rowbias + (long long)s_first * p.ldrb + ocol;
+      const float* r1 = p.rowbias + (long long)min(s_first + 1, s_last) * p.ldrb + ocol;
+      rb[0][0] = *(const f32x4*)r0; rb[0][1] = *(const f32x4*)(r0 + 4);
+      rb[1][0] = *(const f32x4*)r1; rb[1][1] = *(const f32x4*)(r1 + 4);
+    }
+  }
+  if (fl & SDMI_F_RESIDUAL) {
+    const u16* rbase = p.res + (long long)bz * p.sc + ocol;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int m = min(row0 + i * 16 + ps * RPP + rrow, p.M - 1);
+        rres[i * PASSES + ps] = *(const u32x4*)(rbase + (long long)m * p.ldr);
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < MT * PASSES; ++q) rres[q] = u32x4{0u, 0u, 0u, 0u};
+  }
+  const int s_split = (s_first + 1) * hwo;  // first row of the second sample
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if constexpr (GEGLU) {
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = acc[i][j][e] * p.alpha + gb[j][e], gv = acc[i][j + 1][e] * p.alpha + gb[j + 1][e];
+          y[e] = xv * gelu_erf(gv);
+        }
+        *(f32x4*)&wreg[l15 * W + (j >> 1) * 16 + lq * 4] = y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) *(f32x4*)&wreg[l15 * W + j * 16 + lq * 4] = acc[i][j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int rl = ps * RPP + rrow;
+      const int m = row0 + i * 16 + rl;
+      const f32x4 v0 = *(const f32x4*)&wreg[rl * W + c * 8], v1 = *(const f32x4*)&wreg[rl * W + c * 8 + 4];
+      float y[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if constexpr (!GEGLU) {
+        const int sel = ((fl & SDMI_F_ROWBIAS) && m >= s_split) ? 1 : 0;
+        const u32x4 rv = rres[i * PASSES + ps];
+        float r[8];
+        unpack2(rv[0], r[0], r[1]); unpack2(rv[1], r[2], r[3]); unpack2(rv[2], r[4], r[5]); unpack2(rv[3], r[6], r[7]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = y[e] * p.alpha;
+          if (fl & SDMI_F_BIAS) t += bia[e >> 2][e & 3];
+          if (fl & SDMI_F_ROWBIAS) t += sel ? rb[1][e >> 2][e & 3] : rb[0][e >> 2][e & 3];
+          if (fl & SDMI_F_RESIDUAL) t += r[e];
+          y[e] = t;
+        }
+      }
+      if (m < p.M && cvalid) {
+        if (fl & SDMI_F_OUT_F32) {
+          float* o = (float*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + ocol;
+          *(f32x4*)o = f32x4{y[0], y[1], y[2], y[3]};
+          *(f32x4*)(o + 4) = f32x4{y[4], y[5], y[6], y[7]};
+        } else {
+          u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + ocol;
+          *(u32x4*)o = u32x4{pack2h(y[0], y[1]), pack2h(y[2], y[3]), pack2h(y[4], y[5]), pack2h(y[6], y[7])};
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -291,6 +421,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
     return;
   }
+  if (p.fast_epi) {
+    if constexpr (NSTAGE > 2) __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed: LDS is free
+    float* wreg = (float*)smem + wv * (16 * (BN / 2 + 4));
+    if constexpr (BN == 128) {
+      if (fl & SDMI_F_GEGLU) { epilogue_fast<BM, BN, true>(p, wreg, acc, bz, brow, bcol, wr, wc, lane); return; }
+    }
+    epilogue_fast<BM, BN, false>(p, wreg, acc, bz, brow, bcol, wr, wc, lane);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = brow + wr * (BM / 2) + i * 16 + l15;
@@ -374,6 +513,16 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   const bool bm128 = p.M > 64 && tiles128 >= 256;
   const int bm = bm128 ? 128 : 64;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+  {
+    const uint32_t fl = p.flags;
+    const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    bool fast = !(fl & SDMI_F_OUT_NCHW_F32) && p.N % 8 == 0 && p.ldc % 8 == 0 && al16(p.out) && p.sc % 8 == 0;
+    if (fl & SDMI_F_GEGLU) fast = fast && bn == 128 && p.N % 32 == 0;
+    if (fl & SDMI_F_BIAS) fast = fast && al16(p.bias);
+    if (fl & SDMI_F_ROWBIAS) fast = fast && al16(p.rowbias) && p.ldrb % 4 == 0 && p.rows_per_sample >= bm;
+    if (fl & SDMI_F_RESIDUAL) fast = fast && al16(p.res) && p.ldr % 8 == 0;
+    p.fast_epi = fast ? 1 : 0;
+  }
   dim3 grid(nb, batch, p.splits), block(256);
   // big tiles: 2 slots (2 blocks of 64 KB per CU, the MFMAs of the co-resident block cover the DMA latency);
   // small-M tiles run on under-filled grids where nothing else covers it: 3 slots, 2 K-tiles in flight
