@@ -29,6 +29,8 @@ struct IgemmParams {
   // split-K: grid.z splits of kt_per_split K-tiles each write fp32 partials [split][batch][M][npad] to ws
   int splits, kt_per_split, npad;
   float* ws;
+  int dbg;       // SDMI_DEBUG_ABLATE bits (experiments only): 1 = no staging inside the K loop, 2 = no MFMA / fragment reads
+  unsigned long long* tbuf;  // SDMI_DEBUG_ABLATE & 16: per-block timestamps
   int fast_epi;  // host-checked: shapes / alignments allow the LDS-transposed 16-byte epilogue
 };
 
@@ -105,114 +107,133 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
 
 // ---- fast epilogue.  The MFMA layout leaves a lane with 4 channels of one row (8-byte pieces, a dependent bias /
 // residual load each).  Instead every wave transposes its accumulators through a private LDS strip, 16 rows at a time,
-// so that a lane owns 8 consecutive channels of a row: bias / per-sample bias / residual arrive as 16-byte loads that
-// are all issued up front (one wait), and the stores are 16 bytes per lane over whole 64- or 128-byte row segments.
-// Arithmetic order per element is that of epilogue4 (alpha, bias, per-sample bias, residual).
-template <int BM, int BN, bool GEGLU>
-__device__ __forceinline__ void epilogue_fast(const IgemmParams& p, float* wreg, f32x4 (&acc)[BM / 32][BN / 32], int bz,
-                                              int brow, int bcol, int wr, int wc, int lane) {
-  constexpr int MT = BM / 32, NT = BN / 32;
-  constexpr int OW = GEGLU ? BN / 4 : BN / 2;  // output columns of this wave per row
-  constexpr int W = OW + 4;                    // padded strip row (floats)
-  constexpr int CH = OW / 8;                   // 8-channel chunks per row
-  constexpr int RPP = 64 / CH;                 // rows per pass
-  constexpr int PASSES = 16 / RPP;
+// so that a lane owns 8 consecutive channels of a row: bias / per-sample bias / residual are 16-byte loads issued
+// BEFORE the K loop (epi_prefetch: they land under the main loop, the epilogue never waits on memory), and the
+// stores are 16 bytes per lane over whole 64- or 128-byte row segments.  Arithmetic order per element is that of
+// epilogue4 (alpha, bias, per-sample bias, residual).
+template <int TM, int TN, bool GEGLU>
+struct EpiRegs {
+  static constexpr int MT = TM / 16, NT = TN / 16;
+  static constexpr int OW = GEGLU ? TN / 2 : TN;  // output columns of this wave per row
+  static constexpr int W = OW + 4;                // padded strip row (floats)
+  static constexpr int CH = OW / 8;               // 8-channel chunks per row
+  static constexpr int RPP = 64 / CH;             // rows per pass
+  static constexpr int PASSES = 16 / RPP;
   static_assert(RPP <= 16, "strip is 16 rows");
-  const uint32_t fl = p.flags;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int rrow = lane / CH, c = lane % CH;
-  const int nout = GEGLU ? p.N >> 1 : p.N;
-  const int colbase = GEGLU ? (bcol + wc * (BN / 2)) >> 1 : bcol + wc * (BN / 2);
-  const bool cvalid = colbase + c * 8 < nout;
-  const int ocol = cvalid ? colbase + c * 8 : 0;
-  const int row0 = brow + wr * (BM / 2);
-  const int hwo = p.rows_per_sample;
-
-  // everything that comes from memory is requested first
-  f32x4 bia[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 bia[2];
   f32x4 gb[GEGLU ? NT : 1];  // GEGLU: value / gate bias in MFMA layout
-  f32x4 rb[2][2] = {{bia[0], bia[0]}, {bia[0], bia[0]}};
-  u32x4 rres[MT * PASSES];
+  f32x4 rb[2][2];            // per-sample bias of the (at most two) samples the tile touches
+  u32x4 rres[MT * PASSES];   // residual, 8 channels per (16-row step, pass)
+  int s_split;               // first row of the second sample
+};
+
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void epi_prefetch(const IgemmParams& p, EpiRegs<TM, TN, GEGLU>& r, int bz, int row0, int col0, int lane) {
+  using R = EpiRegs<TM, TN, GEGLU>;
+  const uint32_t fl = p.flags;
+  const int lq = lane >> 4;
+  const int rrow = lane / R::CH, c = lane % R::CH;
+  const int nout = GEGLU ? p.N >> 1 : p.N;
+  const int colbase = GEGLU ? col0 >> 1 : col0;
+  const int ocol = colbase + c * 8 < nout ? colbase + c * 8 : 0;
+  const int hwo = p.rows_per_sample;
+  const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+  r.bia[0] = r.bia[1] = z;
+  r.rb[0][0] = r.rb[0][1] = r.rb[1][0] = r.rb[1][1] = z;
   int s_first = 0;
   if constexpr (GEGLU) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) gb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < R::NT; ++j) r.gb[j] = z;
     if (fl & SDMI_F_BIAS) {
 #pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        const int nb0 = bcol + wc * (BN / 2) + j * 16;
+      for (int j = 0; j < R::NT; j += 2) {
+        const int nb0 = col0 + j * 16;
         const int oc = nb0 < p.N ? (nb0 >> 5) * 16 + lq * 4 : 0;
-        gb[j] = *(const f32x4*)(p.bias + oc);
-        gb[j + 1] = *(const f32x4*)(p.bias + nout + oc);
+        r.gb[j] = *(const f32x4*)(p.bias + oc);
+        r.gb[j + 1] = *(const f32x4*)(p.bias + nout + oc);
       }
     }
   } else {
+    r.gb[0] = z;
     if (fl & SDMI_F_BIAS) {
-      bia[0] = *(const f32x4*)(p.bias + ocol);
-      bia[1] = *(const f32x4*)(p.bias + ocol + 4);
+      r.bia[0] = *(const f32x4*)(p.bias + ocol);
+      r.bia[1] = *(const f32x4*)(p.bias + ocol + 4);
     }
     if (fl & SDMI_F_ROWBIAS) {  // host guarantees rows_per_sample >= BM: a tile touches at most two samples
       s_first = row0 / hwo;
       const int s_last = (p.M - 1) / hwo;
       const float* r0 = p.rowbias + (long long)s_first * p.ldrb + ocol;
       const float* r1 = p.rowbias + (long long)min(s_first + 1, s_last) * p.ldrb + ocol;
-      rb[0][0] = *(const f32x4*)r0; rb[0][1] = *(const f32x4*)(r0 + 4);
-      rb[1][0] = *(const f32x4*)r1; rb[1][1] = *(const f32x4*)(r1 + 4);
+      r.rb[0][0] = *(const f32x4*)r0; r.rb[0][1] = *(const f32x4*)(r0 + 4);
+      r.rb[1][0] = *(const f32x4*)r1; r.rb[1][1] = *(const f32x4*)(r1 + 4);
     }
   }
   if (fl & SDMI_F_RESIDUAL) {
     const u16* rbase = p.res + (long long)bz * p.sc + ocol;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < R::MT; ++i)
 #pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
-        const int m = min(row0 + i * 16 + ps * RPP + rrow, p.M - 1);
-        rres[i * PASSES + ps] = *(const u32x4*)(rbase + (long long)m * p.ldr);
+      for (int ps = 0; ps < R::PASSES; ++ps) {
+        const int m = min(row0 + i * 16 + ps * R::RPP + rrow, p.M - 1);
+        r.rres[i * R::PASSES + ps] = *(const u32x4*)(rbase + (long long)m * p.ldr);
       }
   } else {
 #pragma unroll
-    for (int q = 0; q < MT * PASSES; ++q) rres[q] = u32x4{0u, 0u, 0u, 0u};
+    for (int q = 0; q < R::MT * R::PASSES; ++q) r.rres[q] = u32x4{0u, 0u, 0u, 0u};
   }
-  const int s_split = (s_first + 1) * hwo;  // first row of the second sample
+  r.s_split = (s_first + 1) * hwo;
+}
 
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void epi_finish(const IgemmParams& p, const EpiRegs<TM, TN, GEGLU>& r, float* wreg,
+                                           f32x4 (&acc)[TM / 16][TN / 16], int bz, int row0, int col0, int lane) {
+  using R = EpiRegs<TM, TN, GEGLU>;
+  constexpr int W = R::W;
+  const uint32_t fl = p.flags;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int rrow = lane / R::CH, c = lane % R::CH;
+  const int nout = GEGLU ? p.N >> 1 : p.N;
+  const int colbase = GEGLU ? col0 >> 1 : col0;
+  const bool cvalid = colbase + c * 8 < nout;
+  const int ocol = cvalid ? colbase + c * 8 : 0;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  for (int i = 0; i < R::MT; ++i) {
     if constexpr (GEGLU) {
 #pragma unroll
-      for (int j = 0; j < NT; j += 2) {
+      for (int j = 0; j < R::NT; j += 2) {
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float xv = acc[i][j][e] * p.alpha + gb[j][e], gv = acc[i][j + 1][e] * p.alpha + gb[j + 1][e];
+          const float xv = acc[i][j][e] * p.alpha + r.gb[j][e], gv = acc[i][j + 1][e] * p.alpha + r.gb[j + 1][e];
           y[e] = xv * gelu_erf(gv);
         }
         *(f32x4*)&wreg[l15 * W + (j >> 1) * 16 + lq * 4] = y;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) *(f32x4*)&wreg[l15 * W + j * 16 + lq * 4] = acc[i][j];
+      for (int j = 0; j < R::NT; ++j) *(f32x4*)&wreg[l15 * W + j * 16 + lq * 4] = acc[i][j];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // wave-private strip: LDS operations of one wave complete in order, so a counter wait (not a fence, which would
+    // also wait for the global stores of the previous pass) is all that separates the writes from the reads
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int rl = ps * RPP + rrow;
+    for (int ps = 0; ps < R::PASSES; ++ps) {
+      const int rl = ps * R::RPP + rrow;
       const int m = row0 + i * 16 + rl;
       const f32x4 v0 = *(const f32x4*)&wreg[rl * W + c * 8], v1 = *(const f32x4*)&wreg[rl * W + c * 8 + 4];
       float y[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if constexpr (!GEGLU) {
-        const int sel = ((fl & SDMI_F_ROWBIAS) && m >= s_split) ? 1 : 0;
-        const u32x4 rv = rres[i * PASSES + ps];
-        float r[8];
-        unpack2(rv[0], r[0], r[1]); unpack2(rv[1], r[2], r[3]); unpack2(rv[2], r[4], r[5]); unpack2(rv[3], r[6], r[7]);
+        // absent terms are zeros (adding +0 changes nothing that survives the fp16 rounding)
+        const bool second = m >= r.s_split;
+        const f32x4 rs0 = second ? r.rb[1][0] : r.rb[0][0], rs1 = second ? r.rb[1][1] : r.rb[0][1];
+        const u32x4 rv = r.rres[i * R::PASSES + ps];
+        float q[8];
+        unpack2(rv[0], q[0], q[1]); unpack2(rv[1], q[2], q[3]); unpack2(rv[2], q[4], q[5]); unpack2(rv[3], q[6], q[7]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = y[e] * p.alpha;
-          if (fl & SDMI_F_BIAS) t += bia[e >> 2][e & 3];
-          if (fl & SDMI_F_ROWBIAS) t += sel ? rb[1][e >> 2][e & 3] : rb[0][e >> 2][e & 3];
-          if (fl & SDMI_F_RESIDUAL) t += r[e];
-          y[e] = t;
+        for (int e = 0; e < 4; ++e) {
+          y[e] = ((y[e] * p.alpha + r.bia[0][e]) + rs0[e]) + q[e];
+          y[e + 4] = ((y[e + 4] * p.alpha + r.bia[1][e]) + rs1[e]) + q[e + 4];
         }
       }
       if (m < p.M && cvalid) {
@@ -226,17 +247,27 @@ __device__ __forceinline__ void epilogue_fast(const IgemmParams& p, float* wreg,
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-template <int BM, int BN, bool CONV, int NSTAGE>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-  constexpr int MT = BM / 32, NT = BN / 32, PA = BM / 32, PB = BN / 32;
+// The second launch bound (2 waves per SIMD for the 4-wave tiles = the 256-register budget they run at anyway) matters:
+// with the default 512-register budget hipcc split the accumulators over VGPRs and AGPRs and shuffled them with 74
+// v_accvgpr moves per K-tile in the plain-GEMM instantiations (MFMA not accumulating in place).
+// GEGLU is a template parameter, not a run-time flag: with the value/gate pairing of accumulators in the same kernel as
+// the plain epilogue, hipcc's register coalescing gave up on in-place MFMA accumulation (74 v_accvgpr moves per K-tile).
+template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, bool GEGLU>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
+  constexpr int NTH = 64 * WM * WN, RP = NTH / 8;          // threads; tile rows staged per DMA pass
+  constexpr int TM = BM / WM, TN = BN / WN;                // wave tile
+  constexpr int MT = TM / 16, NT = TN / 16, PA = BM / RP, PB = BN / RP;
+  static_assert(BM % RP == 0 && BN % RP == 0 && TM % 16 == 0 && TN % 16 == 0, "tile / wave grid mismatch");
   constexpr int STAGE = (BM + BN) * BK;  // elements per pipeline stage
-  __shared__ __attribute__((aligned(16))) u16 smem[NSTAGE * STAGE];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1, l15 = lane & 15, lq = lane >> 4;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];  // NSTAGE * STAGE halves (the only LDS object)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv / WN, wc = wv % WN, l15 = lane & 15, lq = lane >> 4;
+  unsigned long long ts[6];
+  ts[0] = __builtin_amdgcn_s_memtime();
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int brow = (bid / tiles_n) * BM, bcol = (bid % tiles_n) * BN;
@@ -250,7 +281,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // fills physical chunk (t&7) of its row fetches logical chunk (t&7)^f(row).  Out-of-range rows / taps / k-chunks
   // fetch 16 zero bytes from g_zero16, so every load is unconditional.
   const u16* const zp = (const u16*)g_zero16;
-  const int r0 = t >> 3;                       // tile row of pass 0 (pass i adds 32)
+  const int r0 = t >> 3;                       // tile row of pass 0 (pass i adds RP)
   const int lchunk = (t & 7) ^ ((r0 >> 1) & 7);  // logical 16-B chunk this lane fetches: f(row) = (row>>1)&7
   const int wave_row0 = __builtin_amdgcn_readfirstlane(wv) * 8;
 
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   int a_oy[PA], a_ox[PA];         // CONV with upsample only
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int gm = brow + r0 + 32 * i;
+    const int gm = brow + r0 + RP * i;
     const bool ok = gm < p.M;
     const int gmc = ok ? gm : 0;
     if constexpr (CONV) {
@@ -293,7 +324,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const u16* b_ptr[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    const int gn = bcol + r0 + 32 * i;
+    const int gn = bcol + r0 + RP * i;
     b_ok[i] = gn < p.N;
     b_ptr[i] = Wp + (long long)(b_ok[i] ? gn : 0) * p.ldw + lchunk * 8;
   }
@@ -322,20 +353,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           const int iy = (a_oy[i] + ky - p.pad_t) >> 1, ix = (a_ox[i] + kx - p.pad_l) >> 1;                       \
           const bool ok = (a_mask[i] & tbit) && cok;                                                              \
           const u16* src = ok ? a_ptr[i] + ((long long)(iy * p.W + ix) * p.lda + c0) : zp;                        \
-          IGEMM_GLDS(src, dA + i * 32 * BK);                                                                      \
+          IGEMM_GLDS(src, dA + i * RP * BK);                                                                      \
         }                                                                                                         \
       } else {                                                                                                    \
         const long long toff = (long long)(ky * p.W + kx) * p.lda + c0;                                           \
         _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                          \
           const bool ok = (a_mask[i] & tbit) && cok;                                                              \
           const u16* src = ok ? a_ptr[i] + toff : zp;                                                             \
-          IGEMM_GLDS(src, dA + i * 32 * BK);                                                                      \
+          IGEMM_GLDS(src, dA + i * RP * BK);                                                                      \
         }                                                                                                         \
       }                                                                                                           \
       const int wk = tap * p.Cin + c0;                                                                            \
       _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                            \
         const u16* src = (b_ok[i] && cok) ? b_ptr[i] + wk : zp;                                                   \
-        IGEMM_GLDS(src, dB + i * 32 * BK);                                                                        \
+        IGEMM_GLDS(src, dB + i * RP * BK);                                                                        \
       }                                                                                                           \
       if (++cb == p.kt_per_tap) { cb = 0; ++tap; }                                                                \
     } else {                                                                                                      \
@@ -343,19 +374,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       const bool kok = live && ko < k_lim;                                                                        \
       _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                            \
         const u16* src = (a_mask[i] && kok) ? a_ptr[i] + ko : zp;                                                 \
-        IGEMM_GLDS(src, dA + i * 32 * BK);                                                                        \
+        IGEMM_GLDS(src, dA + i * RP * BK);                                                                        \
       }                                                                                                           \
       _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                            \
         const u16* src = (b_ok[i] && kok) ? b_ptr[i] + ko : zp;                                                   \
-        IGEMM_GLDS(src, dB + i * 32 * BK);                                                                        \
+        IGEMM_GLDS(src, dB + i * RP * BK);                                                                        \
       }                                                                                                           \
     }                                                                                                             \
   }
   // wait until all but the NSTAGE-2 youngest stage groups of THIS wave have landed and this wave's fragment reads of
   // the slot that is restaged next have returned (lgkmcnt), then meet the other waves
-#define IGEMM_WAIT_STAGE()                                                                          \
+#define IGEMM_WAIT_STAGE(GROUPS)                                                                    \
   {                                                                                                 \
-    constexpr int INFLIGHT = (NSTAGE - 2) * (PA + PB);                                              \
+    constexpr int INFLIGHT = (GROUPS) * (PA + PB);                                                  \
     if constexpr (INFLIGHT == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
     else if constexpr (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   \
     else if constexpr (INFLIGHT == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   \
@@ -372,35 +403,57 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // NSTAGE-slot ring, prefetch distance NSTAGE-1: the DMA of tiles k+1..k+NSTAGE-1 is in flight over the MFMAs of
-  // tile k (one counted vmcnt + one raw s_barrier per K-tile; __syncthreads() would drain the DMA queue).
+  // NSTAGE-slot ring.  Fragments are double-buffered in registers and the loop is skewed by half a K-tile, so every
+  // ds_read batch is issued ahead of an MFMA batch that does not depend on it (the LDS latency hides under 16+ MFMAs)
+  // and a K-tile costs one counted s_waitcnt + one raw s_barrier (__syncthreads() would drain the DMA queue):
+  //   read kk=1 of tile k | MFMA kk=0 of tile k | wait: tile k+1 landed, slot of tile k fully read; barrier |
+  //   stage tile k+NSTAGE into the slot of tile k | read kk=0 of tile k+1 | MFMA kk=1 of tile k
+#define IGEMM_READ_FRAGS(AF, WF, SLOT, KK)                                                                       \
+  {                                                                                                              \
+    const u16* cA = smem + (SLOT) * STAGE;                                                                       \
+    const u16* cB = cA + BM * BK;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) AF[i] = *(const hx8*)&cA[lds_off(wr * TM + i * 16 + l15, lq + 4 * (KK))]; \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const hx8*)&cB[lds_off(wc * TN + j * 16 + l15, lq + 4 * (KK))]; \
+  }
+#define IGEMM_MFMA_ALL(AF, WF)                                                                 \
+  {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                             \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(WF[j], AF[i], acc[i][j], 0, 0, 0); \
+  }
+  hx8 af0[MT], wf0[NT], af1[MT], wf1[NT];
+  if (p.dbg & 4) return;
+  // epilogue operands first: they are in registers long before the K loop ends
+  constexpr bool FAST_OK = !GEGLU || TN >= 64;
+  EpiRegs<TM, FAST_OK ? TN : 64, GEGLU> er;
+  const bool fast = FAST_OK && p.fast_epi && p.splits == 1;
+  if constexpr (FAST_OK) if (fast) epi_prefetch<TM, TN, GEGLU>(p, er, bz, brow + wr * TM, bcol + wc * TN, lane);
 #pragma unroll
-  for (int sidx = 0; sidx < NSTAGE - 1; ++sidx) IGEMM_STAGE_TILE(kt_begin + sidx, sidx);
-  IGEMM_WAIT_STAGE();
+  for (int sidx = 0; sidx < NSTAGE; ++sidx) IGEMM_STAGE_TILE(kt_begin + sidx, sidx);
+  IGEMM_WAIT_STAGE(NSTAGE - 1);  // tile kt_begin has landed, NSTAGE-1 younger ones are in flight
+  ts[1] = __builtin_amdgcn_s_memtime();
+  IGEMM_READ_FRAGS(af0, wf0, 0, 0);
   int slot = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    int nslot = slot + NSTAGE - 1;
-    if (nslot >= NSTAGE) nslot -= NSTAGE;
-    IGEMM_STAGE_TILE(kt + NSTAGE - 1, nslot);
-    const u16* cA = smem + slot * STAGE;
-    const u16* cB = cA + BM * BK;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ch = lq + 4 * kk;
-      hx8 af[MT], wf[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const hx8*)&cA[lds_off(wr * (BM / 2) + i * 16 + l15, ch)];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *(const hx8*)&cB[lds_off(wc * (BN / 2) + j * 16 + l15, ch)];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    if (!(p.dbg & 2)) {
+      IGEMM_READ_FRAGS(af1, wf1, slot, 1);
+      IGEMM_MFMA_ALL(af0, wf0);
     }
-    IGEMM_WAIT_STAGE();
-    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    IGEMM_WAIT_STAGE(NSTAGE - 2);
+    if (!(p.dbg & 1)) IGEMM_STAGE_TILE(kt + NSTAGE, slot);
+    if (!(p.dbg & 2)) {
+      IGEMM_READ_FRAGS(af0, wf0, nslot, 0);
+      IGEMM_MFMA_ALL(af1, wf1);
+    }
+    slot = nslot;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (zero-page) DMA must land before the LDS is released
+  // trailing (zero-page) DMAs of every wave must land before the epilogue reuses the LDS
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  ts[2] = __builtin_amdgcn_s_memtime();
+  if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) ((float*)p.out)[0] = 1.f; return; }
+#undef IGEMM_READ_FRAGS
+#undef IGEMM_MFMA_ALL
 #undef IGEMM_STAGE_TILE
 #undef IGEMM_WAIT_STAGE
 #undef IGEMM_GLDS
@@ -411,34 +464,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     float* wsb = p.ws + ((long long)blockIdx.z * gridDim.y + bz) * p.M * p.npad;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m = brow + wr * (BM / 2) + i * 16 + l15;
+      const int m = brow + wr * TM + i * 16 + l15;
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n0 = bcol + wc * (BN / 2) + j * 16 + lq * 4;
+        const int n0 = bcol + wc * TN + j * 16 + lq * 4;
         if (n0 < p.npad) *(float4*)(wsb + (long long)m * p.npad + n0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }
     return;
   }
-  if (p.fast_epi) {
-    if constexpr (NSTAGE > 2) __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed: LDS is free
-    float* wreg = (float*)smem + wv * (16 * (BN / 2 + 4));
-    if constexpr (BN == 128) {
-      if (fl & SDMI_F_GEGLU) { epilogue_fast<BM, BN, true>(p, wreg, acc, bz, brow, bcol, wr, wc, lane); return; }
+  if constexpr (FAST_OK) if (fast) {
+    float* wreg = (float*)smem + wv * (16 * (TN + 4));
+    epi_finish<TM, TN, GEGLU>(p, er, wreg, acc, bz, brow + wr * TM, bcol + wc * TN, lane);
+    if (p.dbg & 16) {
+      ts[3] = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ts[4] = __builtin_amdgcn_s_memtime();
+      if (t == 0) {
+        unsigned long long* o = p.tbuf + (size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8;
+        o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3]; o[4] = ts[4];
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[5] = hwid; o[6] = xcc;
+      }
     }
-    epilogue_fast<BM, BN, false>(p, wreg, acc, bz, brow, bcol, wr, wc, lane);
     return;
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = brow + wr * (BM / 2) + i * 16 + l15;
+    const int m = brow + wr * TM + i * 16 + l15;
     if (m >= p.M) continue;
-    if (fl & SDMI_F_GEGLU) {
+    if constexpr (GEGLU) {
       const int half = p.N >> 1;
 #pragma unroll
       for (int j = 0; j < NT; j += 2) {
-        const int nb0 = bcol + wc * (BN / 2) + j * 16;
+        const int nb0 = bcol + wc * TN + j * 16;
         if (nb0 >= p.N) continue;
         const int oc = (nb0 >> 5) * 16 + lq * 4;
         float y[4];
@@ -451,14 +512,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + oc;
         *(uint2*)o = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
       }
-      continue;
-    }
+    } else {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n0 = bcol + wc * (BN / 2) + j * 16 + lq * 4;
-      if (n0 >= p.N) continue;
-      float y[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epilogue4(p, bz, m, n0, y);
+      for (int j = 0; j < NT; ++j) {
+        const int n0 = bcol + wc * TN + j * 16 + lq * 4;
+        if (n0 >= p.N) continue;
+        float y[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        epilogue4(p, bz, m, n0, y);
+      }
     }
   }
 }
@@ -493,10 +554,63 @@ static int64_t splitk_ws_bytes(int m, int n, int nk, int batch, int rows_per_sam
   return (int64_t)splits * batch * m * ((n + 3) / 4 * 4) * (int64_t)sizeof(float);
 }
 
+static unsigned long long* g_tbuf = nullptr;
+extern "C" int sdmi_debug_dump(void* host, long long bytes) { return g_tbuf ? (int)hipMemcpy(host, g_tbuf, bytes, hipMemcpyDeviceToHost) : -1; }
+
+// One tile variant: BM x BN block tile, WM x WN waves (wave tile BM/WM x BN/WN), NSTAGE ring slots in dynamic LDS.
+struct TileVariant { int bm, bn, wm, wn, nstage; };
+static const TileVariant kVariants[] = {
+    {256, 128, 4, 2, 3},  // 0: 8 waves x (64 x 64), 144 KB LDS, 1 block / CU, 2 K-tiles in flight
+    {128, 128, 2, 2, 2},  // 1: 4 waves x (64 x 64), 64 KB, 2 blocks / CU
+    {128, 64, 2, 2, 2},   // 2: 48 KB, 3 blocks / CU
+    {64, 128, 2, 2, 3},   // 3
+    {64, 64, 2, 2, 3},    // 4
+};
+
+template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, bool GEGLU>
+static void launch_variant2(dim3 grid, hipStream_t st, const IgemmParams& p) {
+  constexpr int bytes = NSTAGE * (BM + BN) * BK * 2;
+  auto kfn = igemm_kernel<BM, BN, WM, WN, CONV, NSTAGE, GEGLU>;
+  static unsigned long long attr_done = 0;  // per device: > 64 KB of dynamic LDS has to be allowed once
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (bytes > 65536 && !((attr_done >> (dev & 63)) & 1ull)) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    attr_done |= 1ull << (dev & 63);
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(64 * WM * WN), bytes, st, p);
+}
+template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE>
+static void launch_variant(dim3 grid, hipStream_t st, const IgemmParams& p) {
+  if constexpr (!CONV && (BN / WN) % 32 == 0) {
+    if (p.flags & SDMI_F_GEGLU) { launch_variant2<BM, BN, WM, WN, CONV, NSTAGE, true>(grid, st, p); return; }
+  }
+  launch_variant2<BM, BN, WM, WN, CONV, NSTAGE, false>(grid, st, p);
+}
+
+// Tile choice.  The main loop is bound by the L2 -> LDS path (about 70 GB/s per CU), so the biggest tile that still
+// gives every CU a block wins; SDMI_IGEMM_TILE=<index into kVariants> forces one (experiments).
+static int choose_variant(const IgemmParams& p, int batch) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("SDMI_IGEMM_TILE");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced >= 0 && forced < (int)(sizeof(kVariants) / sizeof(kVariants[0]))) {
+    return forced;
+  }
+  const bool bn128 = (p.N % 128 == 0) || (p.N > 512);
+  const int bn = bn128 ? 128 : 64;
+  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * batch * p.splits;
+  const bool bm128 = p.M > 64 && tiles128 >= 256;
+  if (bm128 && bn128) return 1;
+  if (bm128) return 2;
+  if (bn128) return 3;
+  return 4;
+}
+
 template <bool CONV>
 static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
-  // tile choice: wide N tile unless N is small or would waste > ~1/6 of it; halve BM when the grid
-  // would not cover the 256 CUs.
   p.splits = 1;
   p.kt_per_split = p.nk;
   p.npad = (p.N + 3) / 4 * 4;
@@ -507,36 +621,45 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     p.splits = (p.nk + p.kt_per_split - 1) / p.kt_per_split;
     p.ws = (float*)ws;
   }
-  const bool bn128 = (p.N % 128 == 0) || (p.N > 512);
-  const int bn = bn128 ? 128 : 64;
-  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * batch * p.splits;
-  const bool bm128 = p.M > 64 && tiles128 >= 256;
-  const int bm = bm128 ? 128 : 64;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("SDMI_DEBUG_ABLATE"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+    if (dbg & 16) {
+      if (!g_tbuf) (void)hipMalloc((void**)&g_tbuf, 8 * 8 * 65536);
+      p.tbuf = g_tbuf;
+    }
+  }
+  const int vi = choose_variant(p, batch);
+  const TileVariant& tv = kVariants[vi];
+  const int bm = tv.bm, bn = tv.bn;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   {
     const uint32_t fl = p.flags;
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     bool fast = !(fl & SDMI_F_OUT_NCHW_F32) && p.N % 8 == 0 && p.ldc % 8 == 0 && al16(p.out) && p.sc % 8 == 0;
-    if (fl & SDMI_F_GEGLU) fast = fast && bn == 128 && p.N % 32 == 0;
+    if (fl & SDMI_F_GEGLU) fast = fast && bn / tv.wn >= 64 && p.N % 32 == 0;
     if (fl & SDMI_F_BIAS) fast = fast && al16(p.bias);
     if (fl & SDMI_F_ROWBIAS) fast = fast && al16(p.rowbias) && p.ldrb % 4 == 0 && p.rows_per_sample >= bm;
     if (fl & SDMI_F_RESIDUAL) fast = fast && al16(p.res) && p.ldr % 8 == 0;
     p.fast_epi = fast ? 1 : 0;
   }
-  dim3 grid(nb, batch, p.splits), block(256);
-  // big tiles: 2 slots (2 blocks of 64 KB per CU, the MFMAs of the co-resident block cover the DMA latency);
-  // small-M tiles run on under-filled grids where nothing else covers it: 3 slots, 2 K-tiles in flight
-  if (bm128 && bn128) hipLaunchKernelGGL((igemm_kernel<128, 128, CONV, 2>), grid, block, 0, st, p);
-  else if (bm128) hipLaunchKernelGGL((igemm_kernel<128, 64, CONV, 2>), grid, block, 0, st, p);
-  else if (bn128) hipLaunchKernelGGL((igemm_kernel<64, 128, CONV, 3>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((igemm_kernel<64, 64, CONV, 3>), grid, block, 0, st, p);
-  sdmi_note_kernel("igemm_kernel<%d, %d, %s, %d>%s", bm, bn, CONV ? "true" : "false", bm128 ? 2 : 3, p.splits > 1 ? " + igemm_splitk_reduce_kernel" : "");
+  dim3 grid(nb, batch, p.splits);
+  switch (vi) {
+    case 0: launch_variant<256, 128, 4, 2, CONV, 3>(grid, st, p); break;
+    case 1: launch_variant<128, 128, 2, 2, CONV, 2>(grid, st, p); break;
+    case 2: launch_variant<128, 64, 2, 2, CONV, 2>(grid, st, p); break;
+    case 3: launch_variant<64, 128, 2, 2, CONV, 3>(grid, st, p); break;
+    default: launch_variant<64, 64, 2, 2, CONV, 3>(grid, st, p); break;
+  }
+  sdmi_note_kernel("igemm_kernel<%d, %d, %d, %d, %s, %d, %s>%s", bm, bn, tv.wm, tv.wn, CONV ? "true" : "false", tv.nstage,
+                   (p.flags & SDMI_F_GEGLU) ? "true" : "false", p.splits > 1 ? " + igemm_splitk_reduce_kernel" : "");
   int rc = sdmi_check_launch(CONV ? "conv3x3" : "gemm");
   if (rc || p.splits < 2) return rc;
   long long items = (long long)batch * p.M * (p.npad / 4);
   long long rb = (items + 255) / 256;
   if (rb > 4096) rb = 4096;
-  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), block, 0, st, p, batch);
+  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
   return sdmi_check_launch("split-K reduce");
 }
 
