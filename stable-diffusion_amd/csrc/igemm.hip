@@ -5,13 +5,16 @@
 // Replaces nn.Conv2d(k=3) / nn.Linear / nn.Conv2d(k=1) / F.interpolate / F.pad / GEGLU of the reference
 // (layers/ResBlock.py:17-19,:36-37,:67-76; layers/SpatialTransformer.py:22-26,:62-66,:110-129,:199,:204).
 //
-// Structure (gfx950): 256 threads = 4 waves in a 2x2 grid over a BM x BN tile, BK = 64 per stage.  Both operands are
-// K-contiguous and staged by LDS-DMA (global_load_lds_dwordx4, 16 B per lane) into an NSTAGE-slot LDS ring whose XOR swizzle
-// (conflict-free ds_read_b128 fragment reads) is applied on the source address.  Prefetch distance NSTAGE-1: the DMA of
-// tiles k+1..k+NSTAGE-1 is in flight over the MFMAs of tile k, ordered by a counted s_waitcnt vmcnt(N) and one raw s_barrier
-// per K-tile (weights are read once per UNet step, i.e. from HBM: one tile in flight left every K-tile latency-bound).
-// v_mfma_f32_16x16x32_f16 with the WEIGHT fragment as the A operand, so a lane ends up with 4 consecutive output
-// channels of one pixel (8-byte stores).
+// Structure (gfx950): WM x WN waves over a BM x BN tile (table kVariants), BK = 64 per stage.  Both operands are
+// K-contiguous and staged by LDS-DMA (global_load_lds_dwordx4, 16 B per lane) into an NSTAGE-slot LDS ring whose XOR
+// swizzle (conflict-free ds_read_b128 fragment reads) is applied on the source address.  The K loop is ordered by one
+// counted s_waitcnt vmcnt(N) + one raw s_barrier per K-tile, fragments are double-buffered in registers (every
+// ds_read batch is issued ahead of an MFMA batch that does not need it).  v_mfma_f32_16x16x32_f16 with the WEIGHT
+// fragment as the A operand, so a lane ends up with 4 consecutive output channels of one pixel; the epilogue widens
+// that to 8 channels / 128-byte row segments with two ds_swizzle lane exchanges (no LDS memory, no barrier), with its
+// bias / residual operands loaded before the K loop.
+// Measured (per-block phase timers, MI355X): the K loop runs at the L2 -> LDS rate of about 70 GB/s per CU (64 KB in
+// flight per CU), not at the MFMA rate; tile shape and prefetch depth are chosen for that.
 #include <stdlib.h>
 #include "common.h"
 
@@ -29,8 +32,6 @@ struct IgemmParams {
   // split-K: grid.z splits of kt_per_split K-tiles each write fp32 partials [split][batch][M][npad] to ws
   int splits, kt_per_split, npad;
   float* ws;
-  int dbg;       // SDMI_DEBUG_ABLATE bits (experiments only): 1 = no staging inside the K loop, 2 = no MFMA / fragment reads
-  unsigned long long* tbuf;  // SDMI_DEBUG_ABLATE & 16: per-block timestamps
   int fast_epi;  // host-checked: shapes / alignments allow the LDS-transposed 16-byte epilogue
 };
 
@@ -307,8 +308,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
   constexpr int STAGE = (BM + BN) * BK;  // elements per pipeline stage
   extern __shared__ __attribute__((aligned(16))) u16 smem[];  // NSTAGE * STAGE halves (the only LDS object)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv / WN, wc = wv % WN, l15 = lane & 15, lq = lane >> 4;
-  unsigned long long ts[6];
-  ts[0] = __builtin_amdgcn_s_memtime();
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int brow = (bid / tiles_n) * BM, bcol = (bid % tiles_n) * BN;
@@ -462,7 +461,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
       _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(WF[j], AF[i], acc[i][j], 0, 0, 0); \
   }
   hx8 af0[MT], wf0[NT], af1[MT], wf1[NT];
-  if (p.dbg & 4) return;
   // epilogue operands first: they are in registers long before the K loop ends
   constexpr bool FAST_OK = !GEGLU || TN >= 64;
   EpiRegs<TM, FAST_OK ? TN : 64, GEGLU> er;
@@ -471,27 +469,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
 #pragma unroll
   for (int sidx = 0; sidx < NSTAGE; ++sidx) IGEMM_STAGE_TILE(kt_begin + sidx, sidx);
   IGEMM_WAIT_STAGE(NSTAGE - 1);  // tile kt_begin has landed, NSTAGE-1 younger ones are in flight
-  ts[1] = __builtin_amdgcn_s_memtime();
   IGEMM_READ_FRAGS(af0, wf0, 0, 0);
   int slot = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
-    if (!(p.dbg & 2)) {
-      IGEMM_READ_FRAGS(af1, wf1, slot, 1);
-      IGEMM_MFMA_ALL(af0, wf0);
-    }
+    IGEMM_READ_FRAGS(af1, wf1, slot, 1);
+    IGEMM_MFMA_ALL(af0, wf0);
     IGEMM_WAIT_STAGE(NSTAGE - 2);
-    if (!(p.dbg & 1)) IGEMM_STAGE_TILE(kt + NSTAGE, slot);
-    if (!(p.dbg & 2)) {
-      IGEMM_READ_FRAGS(af0, wf0, nslot, 0);
-      IGEMM_MFMA_ALL(af1, wf1);
-    }
+    IGEMM_STAGE_TILE(kt + NSTAGE, slot);
+    IGEMM_READ_FRAGS(af0, wf0, nslot, 0);
+    IGEMM_MFMA_ALL(af1, wf1);
     slot = nslot;
   }
   // this wave's trailing (zero-page) DMAs must land before it exits and its LDS is handed to another block
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  ts[2] = __builtin_amdgcn_s_memtime();
-  if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) ((float*)p.out)[0] = 1.f; return; }
 #undef IGEMM_READ_FRAGS
 #undef IGEMM_MFMA_ALL
 #undef IGEMM_STAGE_TILE
@@ -516,18 +507,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
   }
   if constexpr (FAST_OK) if (fast) {
     epi_finish<TM, TN, GEGLU>(p, er, acc, bz, brow + wr * TM, bcol + wc * TN, lane);
-    if (p.dbg & 16) {
-      ts[3] = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ts[4] = __builtin_amdgcn_s_memtime();
-      if (t == 0) {
-        unsigned long long* o = p.tbuf + (size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8;
-        o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3]; o[4] = ts[4];
-        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        o[5] = hwid; o[6] = xcc;
-      }
-    }
     return;
   }
 #pragma unroll
@@ -593,9 +572,6 @@ static int64_t splitk_ws_bytes(int m, int n, int nk, int batch, int rows_per_sam
   return (int64_t)splits * batch * m * ((n + 3) / 4 * 4) * (int64_t)sizeof(float);
 }
 
-static unsigned long long* g_tbuf = nullptr;
-extern "C" int sdmi_debug_dump(void* host, long long bytes) { return g_tbuf ? (int)hipMemcpy(host, g_tbuf, bytes, hipMemcpyDeviceToHost) : -1; }
-
 // One tile variant: BM x BN block tile, WM x WN waves (wave tile BM/WM x BN/WN), NSTAGE ring slots in dynamic LDS.
 struct TileVariant { int bm, bn, wm, wn, nstage; };
 static const TileVariant kVariants[] = {
@@ -659,15 +635,6 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     p.kt_per_split = (p.nk + s - 1) / s;
     p.splits = (p.nk + p.kt_per_split - 1) / p.kt_per_split;
     p.ws = (float*)ws;
-  }
-  {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("SDMI_DEBUG_ABLATE"); dbg = e ? atoi(e) : 0; }
-    p.dbg = dbg;
-    if (dbg & 16) {
-      if (!g_tbuf) (void)hipMalloc((void**)&g_tbuf, 8 * 8 * 65536);
-      p.tbuf = g_tbuf;
-    }
   }
   const int vi = choose_variant(p, batch);
   const TileVariant& tv = kVariants[vi];
