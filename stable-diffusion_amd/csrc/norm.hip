@@ -14,14 +14,56 @@ __device__ __attribute__((aligned(16))) unsigned g_norm_zero16[4] = {0u, 0u, 0u,
 // (64 when C/8 >= 64, else the next power of two >= C/8), lane -> (row sub-index lane/LPR, 16-byte chunk lane%LPR
 // [+64*s]).  A lane always owns the same channels, so per-channel state (sums, scale/shift) lives in registers.
 
+// fold the per-block partials of sample n (fp64, fixed order) into per-channel scale/shift; one 256-thread block
+__device__ __forceinline__ void gn_fold(const float* partial, int nblk, int groups, int c, int hw,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                        float* __restrict__ scale_shift, int n, float* s_mean, float* s_rstd) {
+  const int t = threadIdx.x;
+  const int g = t >> 3, sub = t & 7;  // 8 threads per group, 32 groups per pass
+  for (int g0 = 0; g0 < groups; g0 += 32) {
+    const int gg = g0 + g;
+    double s0 = 0.0, s1 = 0.0;
+    if (gg < groups)
+      for (int b = sub; b < nblk; b += 8) {
+        const float2 pp = *(const float2*)(partial + (((long long)n * nblk + b) * groups + gg) * 2);
+        s0 += (double)pp.x;
+        s1 += (double)pp.y;
+      }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if (sub == 0 && gg < groups) {
+      const double cnt = (double)hw * (double)(c / groups);
+      const double mean = s0 / cnt;
+      double var = s1 / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[gg & 63] = (float)mean;
+      s_rstd[gg & 63] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  const int cpg = c / groups;
+  for (int ci = t; ci < c; ci += 256) {
+    const int gg = ci / cpg;
+    const float sc = gamma[ci] * s_rstd[gg & 63];
+    float2 o;
+    o.x = sc;
+    o.y = beta[ci] - s_mean[gg & 63] * sc;
+    *(float2*)(scale_shift + ((long long)n * c + ci) * 2) = o;
+  }
+}
+
+
 // pass 1a: per-block partial (sum, sumsq) of every group.  grid (nblk, N).  Per-channel sums in registers, rows
 // sub-indices folded by shuffles, the 4 waves combined through LDS in wave order, thread g folds group g: fixed
 // order everywhere (bit-reproducible).
 template <int NS>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const u16* __restrict__ x, int hw, int c, int ldx,
                                                          int rows_per_block, int cpg, int lpr_shift,
-                                                         float* __restrict__ partial) {
+                                                         float* partial, unsigned* ticket,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float* __restrict__ scale_shift) {
   __shared__ float s_sum[2560], s_sq[2560];
+  __shared__ int s_last;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int blk = blockIdx.x, n = blockIdx.y, nblk = gridDim.x;
   const int cc = c >> 3;
@@ -86,9 +128,32 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const u16* __restrict__
     float s0 = 0.f, s1 = 0.f;
     for (int i = 0; i < cpg; ++i) { s0 += s_sum[t * cpg + i]; s1 += s_sq[t * cpg + i]; }
     float* o = partial + (((long long)n * nblk + blk) * groups + t) * 2;
-    o[0] = s0;
-    o[1] = s1;
+    if (ticket) {  // write-through (agent-scope) stores: visible to the folding block without an L2 write-back fence
+      __hip_atomic_store(o, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      o[0] = s0;
+      o[1] = s1;
+    }
   }
+  if (!ticket) return;  // gn_finalize_kernel follows as its own launch
+  // Last-arriver fold: the block that draws the last ticket of its sample turns the partials into scale/shift (what
+  // gn_finalize_kernel does as a separate launch) and re-arms the ticket for the next call.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(ticket + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == (unsigned)nblk - 1u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(ticket + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  gn_fold(partial, nblk, groups, c, hw, gamma, beta, eps, scale_shift, n, s_sum, s_sq);
 }
 
 // pass 1b: fold the partials (fp64), emit per-(sample,channel) scale/shift.  grid N, 256 threads.
@@ -97,40 +162,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ beta, float eps,
                                                           float* __restrict__ scale_shift) {
   __shared__ float s_mean[64], s_rstd[64];
-  const int t = threadIdx.x, n = blockIdx.x;
-  const int g = t >> 3, sub = t & 7;  // 8 threads per group, 32 groups per pass
-  for (int g0 = 0; g0 < groups; g0 += 32) {
-    const int gg = g0 + g;
-    double s0 = 0.0, s1 = 0.0;
-    if (gg < groups)
-      for (int b = sub; b < nblk; b += 8) {
-        const float2 pp = *(const float2*)(partial + (((long long)n * nblk + b) * groups + gg) * 2);
-        s0 += (double)pp.x;
-        s1 += (double)pp.y;
-      }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
-    if (sub == 0 && gg < groups) {
-      const double cnt = (double)hw * (double)(c / groups);
-      const double mean = s0 / cnt;
-      double var = s1 / cnt - mean * mean;
-      if (var < 0.0) var = 0.0;
-      s_mean[gg & 63] = (float)mean;
-      s_rstd[gg & 63] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
-  const int cpg = c / groups;
-  for (int ci = t; ci < c; ci += 256) {
-    const int gg = ci / cpg;
-    const float sc = gamma[ci] * s_rstd[gg & 63];
-    float2 o;
-    o.x = sc;
-    o.y = beta[ci] - s_mean[gg & 63] * sc;
-    *(float2*)(scale_shift + ((long long)n * c + ci) * 2) = o;
-  }
+  gn_fold(partial, nblk, groups, c, hw, gamma, beta, eps, scale_shift, blockIdx.x, s_mean, s_rstd);
 }
-
 // pass 2: y = act(x*scale + shift).  grid (nblk, N); same lane mapping; the lane's scale/shift stay in registers
 // for all its rows, two passes per wave in flight.
 template <int NS>
@@ -192,6 +225,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x
   }
 }
 
+// Tickets of the last-arriver fold: zero at load, re-armed by the folding block.  64 banks of 256 samples, bank chosen
+// from the workspace address, so GroupNorm calls that overlap in time on one device (different streams) must use
+// different workspaces - calls on one stream, or otherwise ordered, can share anything.
+constexpr int GN_TICKET_SAMPLES = 256, GN_TICKET_BANKS = 64;
+__device__ unsigned g_gn_ticket[GN_TICKET_BANKS * GN_TICKET_SAMPLES];
+
 static int gn_nblk(int hw) {
   int nb = (hw + 31) / 32;
   return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
@@ -223,15 +262,30 @@ extern "C" int sdmi_groupnorm_stats(const void* x, int n, int hw, int c, int ldx
   dim3 grid(nblk, n), block(256);
   const u16* xp = (const u16*)x;
   float* part = (float*)ws;
-  switch (ns) {
-    case 1: hipLaunchKernelGGL(gn_partial_kernel<1>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
-    case 2: hipLaunchKernelGGL(gn_partial_kernel<2>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
-    case 3: hipLaunchKernelGGL(gn_partial_kernel<3>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
-    case 4: hipLaunchKernelGGL(gn_partial_kernel<4>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
-    default: hipLaunchKernelGGL(gn_partial_kernel<5>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part); break;
+  unsigned* ticket = nullptr;
+  if (n <= GN_TICKET_SAMPLES) {
+    static void* sym_of_device[64] = {};  // every device holds its own copy of the array at its own address
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void*& sym = sym_of_device[dev & 63];
+    if (!sym && (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_gn_ticket)) != hipSuccess || !sym)) {
+      sym = nullptr;
+      sdmi_set_error("groupnorm_stats: hipGetSymbolAddress(g_gn_ticket) failed");
+      return SDMI_ELAUNCH;
+    }
+    ticket = (unsigned*)sym + (((uintptr_t)ws >> 8) % GN_TICKET_BANKS) * GN_TICKET_SAMPLES;
   }
+#define GN_PARTIAL(NS) hipLaunchKernelGGL(gn_partial_kernel<NS>, grid, block, 0, st, xp, hw, c, ldx, rpb, c / groups, lsh, part, ticket, gamma, beta, eps, scale_shift)
+  switch (ns) {
+    case 1: GN_PARTIAL(1); break;
+    case 2: GN_PARTIAL(2); break;
+    case 3: GN_PARTIAL(3); break;
+    case 4: GN_PARTIAL(4); break;
+    default: GN_PARTIAL(5); break;
+  }
+#undef GN_PARTIAL
   int rc = sdmi_check_launch("groupnorm partial");
-  if (rc) return rc;
+  if (rc || ticket) return rc;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), block, 0, st, part, nblk, groups, c, hw, gamma, beta, eps, scale_shift);
   return sdmi_check_launch("groupnorm finalize");
 }
