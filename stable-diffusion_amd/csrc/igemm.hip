@@ -32,6 +32,7 @@ struct IgemmParams {
   // split-K: grid.z splits of kt_per_split K-tiles each write fp32 partials [split][batch][M][npad] to ws
   int splits, kt_per_split, npad;
   float* ws;
+  unsigned* ticket;  // split-K: per-tile arrival counters (in-kernel reduction by the last arriver); null = reduce kernel
   int fast_epi;  // host-checked: shapes / alignments allow the LDS-transposed 16-byte epilogue
 };
 
@@ -464,8 +465,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
   // epilogue operands first: they are in registers long before the K loop ends
   constexpr bool FAST_OK = !GEGLU || TN >= 64;
   EpiRegs<TM, FAST_OK ? TN : 64, GEGLU> er;
-  const bool fast = FAST_OK && p.fast_epi && p.splits == 1;
-  if constexpr (FAST_OK) if (fast) epi_prefetch<TM, TN, GEGLU>(p, er, bz, brow + wr * TM, bcol + wc * TN, lane);
+  const bool fast = FAST_OK && p.fast_epi;
+  if constexpr (FAST_OK) if (fast && p.splits == 1) epi_prefetch<TM, TN, GEGLU>(p, er, bz, brow + wr * TM, bcol + wc * TN, lane);
 #pragma unroll
   for (int sidx = 0; sidx < NSTAGE; ++sidx) IGEMM_STAGE_TILE(kt_begin + sidx, sidx);
   IGEMM_WAIT_STAGE(NSTAGE - 1);  // tile kt_begin has landed, NSTAGE-1 younger ones are in flight
@@ -491,7 +492,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
 
   // ---- epilogue: lane holds out[m][n0..n0+3], m = tile row l15, n0 = 4*lq within each 16x16 tile ----
   const uint32_t fl = p.flags;
-  if (p.splits > 1) {  // raw fp32 partials; igemm_splitk_reduce_kernel finishes
+  if (p.splits > 1) {
+    // split-K: every block leaves its fp32 partial tile in the workspace; the block that draws the tile's last ticket
+    // sums all of them in split order (same bits whoever is last) and runs the epilogue.  Hand-off = plain stores,
+    // every wave drained, one agent-scope release before the ticket, one agent-scope acquire after it.
     float* wsb = p.ws + ((long long)blockIdx.z * gridDim.y + bz) * p.M * p.npad;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -503,7 +507,41 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
         if (n0 < p.npad) *(float4*)(wsb + (long long)m * p.npad + n0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }
-    return;
+    if (!p.ticket) return;  // igemm_splitk_reduce_kernel finishes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // all partial stores issued and drained; every wave's trailing DMA has landed, the LDS is free
+    int* flag = (int*)smem;
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned* tk = p.ticket + ((long long)bz * gridDim.x + blockIdx.x);
+      const unsigned prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == (unsigned)p.splits - 1u;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next call
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if constexpr (FAST_OK) if (fast) epi_prefetch<TM, TN, GEGLU>(p, er, bz, brow + wr * TM, bcol + wc * TN, lane);
+    const long long per_split = (long long)gridDim.y * p.M * p.npad;
+    const float* base = p.ws + (long long)bz * p.M * p.npad;
+    for (int s = 0; s < p.splits; ++s) {
+      const float* sb = base + s * per_split;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = min(brow + wr * TM + i * 16 + l15, p.M - 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n0 = min(bcol + wc * TN + j * 16 + lq * 4, p.npad - 4);
+          const f32x4 v = *(const f32x4*)(sb + (long long)m * p.npad + n0);
+          acc[i][j] = s == 0 ? v : acc[i][j] + v;
+        }
+      }
+    }
   }
   if constexpr (FAST_OK) if (fast) {
     epi_finish<TM, TN, GEGLU>(p, er, acc, bz, brow + wr * TM, bcol + wc * TN, lane);
@@ -571,6 +609,12 @@ static int64_t splitk_ws_bytes(int m, int n, int nk, int batch, int rows_per_sam
   const int splits = (nk + kps - 1) / kps;
   return (int64_t)splits * batch * m * ((n + 3) / 4 * 4) * (int64_t)sizeof(float);
 }
+
+// Tickets of the in-kernel split-K reduction: zero at load, re-armed by the reducing block.  16 banks of 4096 tiles,
+// bank chosen from the workspace address: split-K launches that overlap in time on one device (different streams) must
+// use different workspaces; launches on one stream, or otherwise ordered, can share one.
+constexpr int SK_TICKET_TILES = 4096, SK_TICKET_BANKS = 16;
+__device__ unsigned g_sk_ticket[SK_TICKET_BANKS * SK_TICKET_TILES];
 
 // One tile variant: BM x BN block tile, WM x WN waves (wave tile BM/WM x BN/WN), NSTAGE ring slots in dynamic LDS.
 struct TileVariant { int bm, bn, wm, wn, nstage; };
@@ -650,6 +694,22 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     if (fl & SDMI_F_RESIDUAL) fast = fast && al16(p.res) && p.ldr % 8 == 0;
     p.fast_epi = fast ? 1 : 0;
   }
+  p.ticket = nullptr;
+  // Off by default: bit-identical to the reduce kernel on every isolated launch tried, but a full 768x768 UNet pass with it
+  // enabled ended in an illegal-address fault that is not explained yet.  SDMI_SPLITK_INKERNEL=1 opts in.
+  const char* inkernel = getenv("SDMI_SPLITK_INKERNEL");
+  if (p.splits > 1 && (long long)nb * batch <= SK_TICKET_TILES && inkernel && inkernel[0] == '1') {
+    static void* sym_of_device[64] = {};  // every device holds its own copy of the array at its own address
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void*& sym = sym_of_device[dev & 63];
+    if (!sym && (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sk_ticket)) != hipSuccess || !sym)) {
+      sym = nullptr;
+      sdmi_set_error("split-K: hipGetSymbolAddress(g_sk_ticket) failed");
+      return SDMI_ELAUNCH;
+    }
+    p.ticket = (unsigned*)sym + (((uintptr_t)ws >> 8) % SK_TICKET_BANKS) * SK_TICKET_TILES;
+  }
   dim3 grid(nb, batch, p.splits);
   switch (vi) {
     case 0: launch_variant<256, 128, 4, 2, CONV, 3>(grid, st, p); break;
@@ -659,9 +719,9 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     default: launch_variant<64, 64, 2, 2, CONV, 3>(grid, st, p); break;
   }
   sdmi_note_kernel("igemm_kernel<%d, %d, %d, %d, %s, %d, %s>%s", bm, bn, tv.wm, tv.wn, CONV ? "true" : "false", tv.nstage,
-                   (p.flags & SDMI_F_GEGLU) ? "true" : "false", p.splits > 1 ? " + igemm_splitk_reduce_kernel" : "");
+                   (p.flags & SDMI_F_GEGLU) ? "true" : "false", (p.splits > 1 && !p.ticket) ? " + igemm_splitk_reduce_kernel" : "");
   int rc = sdmi_check_launch(CONV ? "conv3x3" : "gemm");
-  if (rc || p.splits < 2) return rc;
+  if (rc || p.splits < 2 || p.ticket) return rc;
   long long items = (long long)batch * p.M * (p.npad / 4);
   long long rb = (items + 255) / 256;
   if (rb > 4096) rb = 4096;
