@@ -6,7 +6,7 @@ from stable_diffusion_amd import engine as E, _lib
 dev = "cuda"; H = E.act_dtype()
 torch.manual_seed(0)
 def run(n, hw, cin, cout, mode):
-    os.environ["SDMI_SPLITK_INKERNEL"] = mode
+    os.environ["SDMI_SPLITK_INKERNEL"] = mode  # read per call by the library
     out = E.new_act(n, hw, hw, cout, dev)
     E.conv3x3(X, W, B, residual=R, out=out)
     torch.cuda.synchronize()

@@ -142,7 +142,8 @@ __device__ __forceinline__ void epi_prefetch(const IgemmParams& p, EpiRegs<TM, T
   const int l15 = lane & 15, lq = lane >> 4;
   const int nout = GEGLU ? p.N >> 1 : p.N;
   const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-  r.s_first = (fl & SDMI_F_ROWBIAS) ? row0 / p.rows_per_sample : 0;
+  // (a wave whose rows all lie past M still prefetches: clamp, or it would read a sample that does not exist)
+  r.s_first = (fl & SDMI_F_ROWBIAS) ? min(row0, p.M - 1) / p.rows_per_sample : 0;
   if constexpr (GEGLU) {
 #pragma unroll
     for (int j = 0; j < R::NT; ++j) r.gb[j] = z;
@@ -494,8 +495,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
   const uint32_t fl = p.flags;
   if (p.splits > 1) {
     // split-K: every block leaves its fp32 partial tile in the workspace; the block that draws the tile's last ticket
-    // sums all of them in split order (same bits whoever is last) and runs the epilogue.  Hand-off = plain stores,
-    // every wave drained, one agent-scope release before the ticket, one agent-scope acquire after it.
+    // sums all of them in split order (same bits whoever is last) and runs the epilogue.  Hand-off = write-through
+    // (sc1) stores, every wave drained, the ticket, one agent-scope acquire in the reducing block.
     float* wsb = p.ws + ((long long)blockIdx.z * gridDim.y + bz) * p.M * p.npad;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -504,7 +505,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n0 = bcol + wc * TN + j * 16 + lq * 4;
-        if (n0 < p.npad) *(float4*)(wsb + (long long)m * p.npad + n0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (n0 < p.npad) {
+          float* dst = wsb + (long long)m * p.npad + n0;
+          if (p.ticket)  // write-through (sc1) store: visible to the reducing block without an L2 write-back fence
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+          else
+            *(f32x4*)dst = acc[i][j];
+        }
       }
     }
     if (!p.ticket) return;  // igemm_splitk_reduce_kernel finishes
@@ -512,8 +519,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void igemm_ke
     __syncthreads();  // all partial stores issued and drained; every wave's trailing DMA has landed, the LDS is free
     int* flag = (int*)smem;
     if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       unsigned* tk = p.ticket + ((long long)bz * gridDim.x + blockIdx.x);
       const unsigned prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = prev == (unsigned)p.splits - 1u;
@@ -695,8 +700,9 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     p.fast_epi = fast ? 1 : 0;
   }
   p.ticket = nullptr;
-  // Off by default: bit-identical to the reduce kernel on every isolated launch tried, but a full 768x768 UNet pass with it
-  // enabled ended in an illegal-address fault that is not explained yet.  SDMI_SPLITK_INKERNEL=1 opts in.
+  // Opt-in (SDMI_SPLITK_INKERNEL=1): bit-identical to the reduce kernel, but measured SLOWER on the UNet step (10.9 ms
+  // against 10.3: the reducing block's serial read of every partial tile plus write-through stores cost more than the
+  // 7-13 us reduce launch they replace; with a release fence instead of write-through stores 11.5 ms).
   const char* inkernel = getenv("SDMI_SPLITK_INKERNEL");
   if (p.splits > 1 && (long long)nb * batch <= SK_TICKET_TILES && inkernel && inkernel[0] == '1') {
     static void* sym_of_device[64] = {};  // every device holds its own copy of the array at its own address

@@ -215,6 +215,20 @@ def test_cfg_ddim_bit_exact():
         assert torch.equal(xc[:b, :4].cpu(), ref) and torch.equal(xc[b:, :4].cpu(), ref) and float(xc[:, 4:].abs().max()) == 0.0
 
 
+def test_conv_rowbias_tile_rows_past_m():
+    """M = 2*144 = 288 rows on 64-row tiles: the last tile's second wave starts past M.  Its epilogue prefetch must not
+    index a per-sample bias row that does not exist (it did once: an out-of-range read that only faulted when the
+    embedding buffer ended an allocation)."""
+    rs = _rs(91)
+    n, cin, cout, h = 2, 64, 256, 12
+    x = _bf(_t(rs.randn(n, cin, h, h)))
+    wt, b = _t(rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)), _t(rs.randn(cout))
+    temb, res = _t(rs.randn(n, cout)), _bf(_t(rs.randn(n, cout, h, h)))
+    ref = F.conv2d(x, _bf(wt), b, padding=1) + temb[:, :, None, None] + res
+    out = E.to_nchw(E.conv3x3(_act(x), torch.nn.Parameter(wt.to(DEV)), b.to(DEV), rowbias=temb.to(DEV), ldrb=cout, residual=_act(res)))
+    _check(out, ref, 1.5e-3, 6e-4, "conv rowbias, rows past M")
+
+
 def test_splitk_conv_and_gemm_batch_invariant():
     """Under-filled grids run split-K (fp32 partials + a fixed-order reduce): parity holds and one image gives the
     same bits alone or inside a batch (the split factor depends on the per-sample shape only)."""
