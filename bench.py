@@ -156,7 +156,7 @@ def main():
     # UNet step latency (graph replay of one forward, CFG batch 2b) on its own
     xc = torch.randn((2 * b, 9, L, L), device=dev)
     tb = torch.full((2 * b,), 501, dtype=torch.long, device=dev)
-    cc = unet.precompute_context(torch.cat([uncond, cond]))
+    cc = sampler.make_context(uncond, cond)
     sampler._unet_step(xc, tb, cc, not args.no_graph)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

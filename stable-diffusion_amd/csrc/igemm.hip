@@ -376,7 +376,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 
   const int kt_begin = blockIdx.z * p.kt_per_split;
   const int kt_end = min(p.nk, kt_begin + p.kt_per_split);
-  int tap = kt_begin / p.kt_per_tap, cb = kt_begin - tap * p.kt_per_tap;  // CONV: position of the NEXT tile to stage
+  // CONV: K-tiles run channel-chunk-major, the 9 taps of one 64-channel chunk back to back: they re-read the same input
+  // patch (shifted), which is then still in the CU's vector cache
+  int cb = kt_begin / 9, tap = kt_begin - cb * 9;  // position of the NEXT tile to stage
 
 #define IGEMM_GLDS(SRC, DST) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
         const u16* src = (b_ok[i] && cok) ? b_ptr[i] + wk : zp;                                                   \
         IGEMM_GLDS(src, dB + i * RP * BK);                                                                        \
       }                                                                                                           \
-      if (++cb == p.kt_per_tap) { cb = 0; ++tap; }                                                                \
+      if (++tap == 9) { tap = 0; ++cb; }                                                                          \
     } else {                                                                                                      \
       const int ko = (KT) * BK;                                                                                   \
       const bool kok = live && ko < k_lim;                                                                        \

@@ -163,14 +163,15 @@ _WS = {}
 
 
 def _workspace(device, nbytes):
-    """Per-device fp32 scratch for split-K partials, grown on demand (kernels on one stream run in order, so one
-    buffer serves every launch).  Returns (ptr, bytes); (0, 0) when nothing is needed."""
+    """Per-(device, stream) fp32 scratch for split-K partials, grown on demand (kernels on one stream run in order, so one
+    buffer serves every launch of that stream).  Returns (ptr, bytes); (0, 0) when nothing is needed."""
     if nbytes <= 0:
         return 0, 0
-    t = _WS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)   # concurrent streams must not share partials
+    t = _WS.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = torch.empty(((max(nbytes, 64 << 20) + 3) // 4,), dtype=torch.float32, device=device)
-        _WS[device] = t
+        _WS[key] = t
     return t.data_ptr(), t.numel() * 4
 
 

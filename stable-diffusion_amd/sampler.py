@@ -9,6 +9,7 @@ caller (the reference draws it from the unseeded global RNG, :211), and the UNet
 HIP graph (shapes are static across steps)."""
 from functools import partial
 
+import os
 import numpy as np
 import torch
 
@@ -38,22 +39,50 @@ def _f32(v):
 
 
 class Sampler(object):
-    def __init__(self, unet, vae=None):
+    def __init__(self, unet, vae=None, dual_stream=None):
         self.unet, self.vae = unet, vae
         self._graph = None
         self._gkey = None
+        # dual_stream: evaluate the unconditional and the conditional half of the CFG batch as two independent UNet
+        # passes on two HIP streams (per-image results do not depend on the batch, so the bits are the same)
+        self.dual_stream = (os.environ.get("SDMI_DUAL_STREAM", "0") == "1") if dual_stream is None else bool(dual_stream)
+        self._side = None
+
+    def make_context(self, uncond, cond):
+        """Step-invariant text-context K/V of the CFG batch [uncond | cond] (one object per half when dual_stream)."""
+        if self.dual_stream:
+            return (self.unet.precompute_context(uncond.contiguous()), self.unet.precompute_context(cond.contiguous()))
+        return self.unet.precompute_context(torch.cat([uncond, cond]).contiguous())
+
+    def _unet_eval(self, xc, t_buf, cc):
+        if not self.dual_stream:
+            return self.unet(xc, timesteps=t_buf, context=cc)
+        b = xc.shape[0] // 2
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            # first use: one pass on the current stream fills the weight pre-pack cache (shared by both streams)
+            self.unet(xc[:b], timesteps=t_buf[:b], context=cc[0])
+            torch.cuda.synchronize()
+            self._side = torch.cuda.Stream()
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            e1 = self.unet(xc[b:], timesteps=t_buf[b:], context=cc[1])
+        e0 = self.unet(xc[:b], timesteps=t_buf[:b], context=cc[0])
+        cur.wait_stream(side)
+        return torch.cat([e0, e1])
 
     # one UNet evaluation on the static buffers, eager or replayed
     def _unet_step(self, xc, t_buf, cc, use_graph):
         if not use_graph:
-            return self.unet(xc, timesteps=t_buf, context=cc)
+            return self._unet_eval(xc, t_buf, cc)
         key = (xc.data_ptr(), t_buf.data_ptr(), id(cc), tuple(xc.shape))
         if self._gkey != key:
-            self.unet(xc, timesteps=t_buf, context=cc)          # warm-up: weight pre-pack, allocator pools
+            self._unet_eval(xc, t_buf, cc)                      # warm-up: weight pre-pack, allocator pools
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self.unet(xc, timesteps=t_buf, context=cc)
+                out = self._unet_eval(xc, t_buf, cc)
             self._graph, self._gout, self._gkey = g, out, key
         self._graph.replay()
         return self._gout
@@ -73,7 +102,7 @@ class Sampler(object):
         xc[:b, 4:] = c_concat
         xc[b:, 4:] = c_concat
         # text-context K/V projections do not depend on the step: project once per prompt
-        cc = self.unet.precompute_context(torch.cat([uncond, cond]).contiguous())
+        cc = self.make_context(uncond, cond)
         t_buf = torch.empty((2 * b,), dtype=torch.long, device=dev)
         x = x_T.clone()
         for i, step in enumerate(np.flip(ts)):
