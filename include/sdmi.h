@@ -104,6 +104,11 @@ int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_
               int64_t ws_bytes, void* stream);
 int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags);
 
+/* tuning hook (benchmarks only; no reference counterpart): force the tile variant (index into the kernel's variant table,
+ * 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64) and / or the split-K factor of every following
+ * sdmi_conv3x3 / sdmi_gemm call of this process; -1 = automatic (the default). */
+void sdmi_tune_override(int tile, int splits);
+
 /* ---- skinny linear for M <= 64 rows: Unet.time_embed (Unet.py:41-45) and every ResBlock.emb_proj
  *      (layers/ResBlock.py:70) batched into one launch. x fp32 [M][K]; w bf16 [N][K]; out fp32 [M][N];
  *      SDMI_F_SILU applies SiLU to x on load. */

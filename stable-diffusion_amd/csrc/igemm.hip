@@ -593,8 +593,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 // Split-K factor.  Depends only on the PER-SAMPLE problem (rows_per_sample, N, K), never on the batch, so one image
 // produces the same bits whether it runs alone or inside a larger batch (the image-sharded multi-GPU path relies on
 // it).  Under-filled grids (few output tiles, long K) are cut so that >= ~384 blocks exist per sample.
-static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags) {
+// tuning override (sdmi_tune_override): -1 = automatic
+static int g_force_tile = -1, g_force_splits = -1;
+extern "C" void sdmi_tune_override(int tile, int splits) { g_force_tile = tile; g_force_splits = splits; }
+
+static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags, bool conv) {
   if (flags & SDMI_F_GEGLU) return 1;
+  if (g_force_splits > 0) return g_force_splits > nk ? nk : g_force_splits;
   static int target = -1;
   if (target < 0) {
     const char* e = getenv("SDMI_SPLITK_TARGET");
@@ -606,13 +611,16 @@ static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags) {
   const long long tiles = (long long)((rows_per_sample + bm - 1) / bm) * ((n + bn - 1) / bn);
   if (tiles > 128) return 1;
   long long s = target / tiles;
-  if (s > nk / 16) s = nk / 16;  // at least 1024 of K per split: below that the fp32 round trip costs more than it buys
+  // at least 1024 of K per split (plain GEMMs: 2048), below that the fp32 round trip costs more than it buys (sweep of
+  // the UNet's shapes, scratch/tune_sweep.py: K = 2560 GEMMs ran 25-35 % faster unsplit)
+  const int min_kt = conv ? 16 : 32;
+  if (s > nk / min_kt) s = nk / min_kt;
   if (s > 16) s = 16;
   return s < 2 ? 1 : (int)s;
 }
 
-static int64_t splitk_ws_bytes(int m, int n, int nk, int batch, int rows_per_sample, uint32_t flags) {
-  const int s = splitk_factor(rows_per_sample, n, nk, flags);
+static int64_t splitk_ws_bytes(int m, int n, int nk, int batch, int rows_per_sample, uint32_t flags, bool conv) {
+  const int s = splitk_factor(rows_per_sample, n, nk, flags, conv);
   if (s < 2) return 0;
   const int kps = (nk + s - 1) / s;
   const int splits = (nk + kps - 1) / kps;
@@ -658,14 +666,24 @@ static void launch_variant(dim3 grid, hipStream_t st, const IgemmParams& p) {
 
 // Tile choice.  The main loop is bound by the L2 -> LDS path (about 70 GB/s per CU), so the biggest tile that still
 // gives every CU a block wins; SDMI_IGEMM_TILE=<index into kVariants> forces one (experiments).
-static int choose_variant(const IgemmParams& p, int batch) {
+static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   static int forced = -2;
   if (forced == -2) {
     const char* e = getenv("SDMI_IGEMM_TILE");
     forced = e ? atoi(e) : -1;
   }
+  if (g_force_tile >= 0 && g_force_tile < (int)(sizeof(kVariants) / sizeof(kVariants[0]))) return g_force_tile;
   if (forced >= 0 && forced < (int)(sizeof(kVariants) / sizeof(kVariants[0]))) {
     return forced;
+  }
+  if (!conv && !(p.flags & SDMI_F_GEGLU)) {
+    // plain GEMMs (K = 320 ... 5120: 5-80 K-tiles, latency-bound): three 128x64 blocks per CU hide the DMA wait better
+    // than two 128x128 ones; grids too small for that run the smallest tile, except long-K wide-N ones (weights are the
+    // traffic there).  From the sweep of the UNet's shapes, scratch/tune_sweep.py.
+    const long long b2 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * batch * p.splits;
+    if (b2 >= 600) return 2;
+    if (p.K >= 2048 && p.N >= 1024) return 3;
+    return 4;
   }
   const bool bn128 = (p.N % 128 == 0) || (p.N > 512);
   const int bn = bn128 ? 128 : 64;
@@ -683,13 +701,13 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   p.kt_per_split = p.nk;
   p.npad = (p.N + 3) / 4 * 4;
   p.ws = nullptr;
-  const int s = splitk_factor(p.rows_per_sample, p.N, p.nk, p.flags);
-  if (s >= 2 && ws && ws_bytes >= splitk_ws_bytes(p.M, p.N, p.nk, batch, p.rows_per_sample, p.flags)) {
+  const int s = splitk_factor(p.rows_per_sample, p.N, p.nk, p.flags, CONV);
+  if (s >= 2 && ws && ws_bytes >= splitk_ws_bytes(p.M, p.N, p.nk, batch, p.rows_per_sample, p.flags, CONV)) {
     p.kt_per_split = (p.nk + s - 1) / s;
     p.splits = (p.nk + p.kt_per_split - 1) / p.kt_per_split;
     p.ws = (float*)ws;
   }
-  const int vi = choose_variant(p, batch);
+  const int vi = choose_variant(p, batch, CONV);
   const TileVariant& tv = kVariants[vi];
   const int bm = tv.bm, bn = tv.bn;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
@@ -799,10 +817,10 @@ extern "C" int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin
 
 extern "C" int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags) {
   if (m <= 0 || n <= 0 || k <= 0 || batch <= 0) return 0;
-  return splitk_ws_bytes(m, n, (k + BK - 1) / BK, batch, rows_per_sample > 0 ? rows_per_sample : m, flags);
+  return splitk_ws_bytes(m, n, (k + BK - 1) / BK, batch, rows_per_sample > 0 ? rows_per_sample : m, flags, false);
 }
 
 extern "C" int64_t sdmi_conv3x3_ws_bytes(int n, int cin, int cout, int hout, int wout) {
   if (n <= 0 || cin <= 0 || cout <= 0 || hout <= 0 || wout <= 0) return 0;
-  return splitk_ws_bytes(n * hout * wout, cout, 9 * ((cin + BK - 1) / BK), 1, hout * wout, 0);
+  return splitk_ws_bytes(n * hout * wout, cout, 9 * ((cin + BK - 1) / BK), 1, hout * wout, 0, true);
 }

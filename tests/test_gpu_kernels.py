@@ -244,7 +244,7 @@ def test_splitk_conv_and_gemm_batch_invariant():
     _check(out, ref, 1.5e-3, 6e-4, "split-K conv")
     one = E.to_nchw(E.conv3x3(_act(x[1:]), W, B, rowbias=TE[1:].contiguous(), ldrb=cout, residual=_act(res[1:])))
     assert torch.equal(one, out[1:])
-    m, nn, k = 288, 1280, 2560
+    m, nn, k = 288, 1280, 5120
     assert L.load().sdmi_gemm_ws_bytes(m, nn, k, 1, 144, 0) > 0
     a, w2 = _bf(_t(rs.randn(m, k))), _bf(_t(rs.randn(nn, k) / np.sqrt(k)))
     A = E.Act(a.to(H16).to(DEV).reshape(2, 144, k), 2, 12, 12, k)
