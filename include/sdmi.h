@@ -67,6 +67,12 @@ int sdmi_groupnorm_stats(const void* x, int n, int hw, int c, int ldx, int group
 int sdmi_groupnorm_apply(const void* x, int ldx, const float* scale_shift, void* y, int ldy, int n, int hw, int c,
                          uint32_t flags, void* stream);
 
+/* GroupNorm(+SiLU) as ONE call (same reference lines).  When a (sample, group) slice (hw * c/groups elements) fits the
+ * registers of one block it runs as a single launch that reads x once (two-pass variance from registers); otherwise it
+ * runs sdmi_groupnorm_stats + sdmi_groupnorm_apply and needs scale_shift (fp32 [N][C][2]) and ws (sdmi_groupnorm_ws_bytes). */
+int sdmi_groupnorm(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups, const float* gamma,
+                   const float* beta, float eps, uint32_t flags, float* scale_shift, void* ws, void* stream);
+
 /* ---- LayerNorm: nn.LayerNorm at layers/SpatialTransformer.py:177-184 ----------------------- */
 int sdmi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
                    int rows, int c, void* stream);

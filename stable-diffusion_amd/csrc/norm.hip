@@ -5,6 +5,7 @@
 //   row softmax           the softmax inside the VAE's single-head attention (:151)
 // All reductions run in a fixed order (no float atomics): results are bit-reproducible run to run and
 // GPU to GPU, which the image-sharded multi-GPU path relies on.
+#include <stdlib.h>
 #include "common.h"
 
 // ------------------------------------------------------------------------------------ GroupNorm
@@ -232,8 +233,10 @@ constexpr int GN_TICKET_SAMPLES = 256, GN_TICKET_BANKS = 64;
 __device__ unsigned g_gn_ticket[GN_TICKET_BANKS * GN_TICKET_SAMPLES];
 
 static int gn_nblk(int hw) {
-  int nb = (hw + 31) / 32;
-  return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+  // 64 rows per block, at most 256 blocks per sample: the fold is paid per arrival (one ticket atomic per block on one
+  // counter, and the folding block's serial pass over the partials): 288 arrivals per sample cost more than they bought
+  int nb = (hw + 63) / 64;
+  return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
 }
 static int gn_lpr_shift(int c) {
   const int cc = c / 8;
@@ -263,7 +266,12 @@ extern "C" int sdmi_groupnorm_stats(const void* x, int n, int hw, int c, int ldx
   const u16* xp = (const u16*)x;
   float* part = (float*)ws;
   unsigned* ticket = nullptr;
-  if (n <= GN_TICKET_SAMPLES) {
+  // SDMI_GN_FOLD=1: last-arriver fold inside the partial kernel instead of the finalize launch.  Off: measured equal or
+  // slightly slower in graph replay (1.09 vs 1.07 ms of GroupNorm per UNet step) - a dependent launch costs ~1.7 us here,
+  // the ticket fan-in plus the acquire cost as much.
+  static int fold_in_kernel = -1;
+  if (fold_in_kernel < 0) { const char* e = getenv("SDMI_GN_FOLD"); fold_in_kernel = (e && e[0] == '1') ? 1 : 0; }
+  if (fold_in_kernel && n <= GN_TICKET_SAMPLES) {
     static void* sym_of_device[64] = {};  // every device holds its own copy of the array at its own address
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -316,6 +324,134 @@ extern "C" int sdmi_groupnorm_apply(const void* x, int ldx, const float* scale_s
     default: hipLaunchKernelGGL(gn_apply_kernel<5>, grid, block, 0, st, xp, ldx, scale_shift, yp, ldy, hw, c, rpb, lsh, silu); break;
   }
   return sdmi_check_launch("groupnorm apply");
+}
+
+
+// ------------------------------------------------------------------------------------ fused GroupNorm (small tensors)
+// One 1024-thread block owns one (sample, group): the group's elements (hw x cpg) sit in registers between the
+// statistics and the normalisation, so the tensor is read once and written once by ONE launch (the three-kernel path
+// reads it twice and pays three dependent launches: 13 us on a 12x12 level, 22 us on 96x96x320, against 4-9 us here).
+// Two-pass variance from registers (exact mean first), fixed reduction order.  4-byte accesses: a group's slice of a
+// row is cpg*2 = 20...160 bytes at a 4-byte-aligned offset.
+template <int DPT>
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const u16* __restrict__ x, int ldx, u16* __restrict__ y, int ldy,
+                                                        int hw, int cpg, int groups, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int silu) {
+  __shared__ float s_red[16];
+  __shared__ float s_sc[160], s_sh[160];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  // blocks b and b+8 share an XCD: give an XCD neighbouring groups (they share the 128-byte lines of a row)
+  int g, n;
+  {
+    const int bid = blockIdx.x, nsamp = gridDim.x / groups;
+    if ((groups & 7) == 0) {
+      const int gpx = groups >> 3, xcd = bid & 7, k = bid >> 3;
+      g = xcd * gpx + k % gpx;
+      n = k / gpx;
+    } else {
+      g = bid % groups;
+      n = bid / groups;
+    }
+    (void)nsamp;
+  }
+  const int dpr = cpg >> 1;  // dwords (channel pairs) per row of this group
+  const int total = hw * dpr;
+  const int qstep = 1024 / dpr, rstep = 1024 - qstep * dpr;
+  const u16* xb = x + (long long)n * hw * ldx + g * cpg;
+  u16* yb = y + (long long)n * hw * ldy + g * cpg;
+  const unsigned* const zp = (const unsigned*)g_norm_zero16;
+  unsigned v[DPT];
+  {
+    int row = t / dpr, d = t - row * dpr;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const bool ok = k * 1024 + t < total;
+      v[k] = *(ok ? (const unsigned*)(xb + (long long)row * ldx + 2 * d) : zp);
+      d += rstep; row += qstep;
+      if (d >= dpr) { d -= dpr; ++row; }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) { float a, b; unpack2(v[k], a, b); s += a + b; }   // masked slots hold zeros
+  s = wave_sum(s);
+  if (lane == 0) s_red[wv] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += s_red[w];
+  const float cnt = (float)hw * (float)cpg;
+  const float mean = tot / cnt;
+  __syncthreads();
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) {
+    float a, b; unpack2(v[k], a, b);
+    const float da = a - mean, db = b - mean;
+    ss += (k * 1024 + t < total) ? da * da + db * db : 0.f;
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) s_red[wv] = ss;
+  __syncthreads();
+  float vtot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) vtot += s_red[w];
+  const float rstd = 1.0f / sqrtf(vtot / cnt + eps);
+  if (t < cpg) {
+    const float sc = gamma[g * cpg + t] * rstd;
+    s_sc[t] = sc;
+    s_sh[t] = beta[g * cpg + t] - mean * sc;
+  }
+  __syncthreads();
+  {
+    // (row, d) are re-derived from an opaque copy of t: otherwise the compiler keeps all DPT load addresses alive
+    // for the stores (3 extra registers per element: spills from DPT = 24 up)
+    int t2 = t;
+    asm volatile("" : "+v"(t2));
+    int row = t2 / dpr, d = t2 - row * dpr;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      float a, b; unpack2(v[k], a, b);
+      float oa = a * s_sc[2 * d] + s_sh[2 * d], ob = b * s_sc[2 * d + 1] + s_sh[2 * d + 1];
+      if (silu) { oa = silu_f(oa); ob = silu_f(ob); }
+      if (k * 1024 + t < total) *(unsigned*)(yb + (long long)row * ldy + 2 * d) = pack2h(oa, ob);
+      d += rstep; row += qstep;
+      if (d >= dpr) { d -= dpr; ++row; }
+    }
+  }
+}
+
+// GroupNorm(+SiLU) in one call: the fused kernel when a (sample, group) fits a block's registers, else stats + apply.
+extern "C" int sdmi_groupnorm(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups, const float* gamma,
+                              const float* beta, float eps, uint32_t flags, float* scale_shift, void* ws, void* stream) {
+  SDMI_REQUIRE(x && y && gamma && beta, "groupnorm: null pointer");
+  SDMI_REQUIRE(n > 0 && hw > 0 && c > 0 && groups > 0 && c % groups == 0, "groupnorm: bad shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  const int cpg = c / groups;
+  static int fused_ok = -1;  // SDMI_GN_FUSED=0 disables the fused kernel (A/B switch)
+  if (fused_ok < 0) { const char* e = getenv("SDMI_GN_FUSED"); fused_ok = (e && e[0] == '0') ? 0 : 1; }
+  const long long dwords = (long long)hw * (cpg / 2);
+  // measured (graph replay, 2 samples): fused 5.9 vs 13.3 us on 12x12x1280, 9.4 vs 14.4 on 24x24x1280, 16.2 vs 20.8 on
+  // 24x24x2560; but 16.9 vs 15.0 on 48x48x640 and 45 vs 21 on 96x96x320 (only N*32 blocks, short row segments)
+  const bool small = dwords <= 12 * 1024 || (dwords <= 24 * 1024 && cpg >= 40);
+  if (fused_ok && small && cpg % 2 == 0 && cpg <= 160 && ldx % 2 == 0 && ldy % 2 == 0 && (long long)n * groups <= 65535 &&
+      (((uintptr_t)x | (uintptr_t)y) & 3) == 0) {
+    hipStream_t st = (hipStream_t)stream;
+    const int dpt = (int)((dwords + 1023) / 1024);
+    dim3 grid(n * groups), block(1024);
+    const int silu = (flags & SDMI_F_SILU) ? 1 : 0;
+    const u16* xp = (const u16*)x;
+    u16* yp = (u16*)y;
+#define GN_FUSED(D) hipLaunchKernelGGL(gn_fused_kernel<D>, grid, block, 0, st, xp, ldx, yp, ldy, hw, cpg, groups, gamma, beta, eps, silu)
+    if (dpt <= 6) GN_FUSED(6);
+    else if (dpt <= 12) GN_FUSED(12);
+    else GN_FUSED(24);
+#undef GN_FUSED
+    return sdmi_check_launch("groupnorm fused");
+  }
+  SDMI_REQUIRE(scale_shift && ws, "groupnorm: this shape needs the scale_shift and workspace buffers");
+  int rc = sdmi_groupnorm_stats(x, n, hw, c, ldx, groups, gamma, beta, eps, scale_shift, ws, stream);
+  if (rc) return rc;
+  return sdmi_groupnorm_apply(x, ldx, scale_shift, y, ldy, n, hw, c, flags, stream);
 }
 
 // ------------------------------------------------------------------------------------ LayerNorm

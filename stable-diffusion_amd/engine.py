@@ -177,15 +177,13 @@ def _workspace(device, nbytes):
 
 # --------------------------------------------------------------------------- ops
 def groupnorm(a, weight, bias, eps, silu, groups=32):
-    """GroupNorm(+SiLU): stats pass + apply pass (csrc/norm.hip)."""
+    """GroupNorm(+SiLU): one fused launch when a (sample, group) slice fits a block, else stats + apply (csrc/norm.hip)."""
     dev = a.device
     ss = torch.empty((a.n, a.c, 2), dtype=torch.float32, device=dev)
     ws = torch.empty((L.load().sdmi_groupnorm_ws_bytes(a.n, a.hw, a.c) // 4,), dtype=torch.float32, device=dev)
-    st = _stream()
-    L.call("sdmi_groupnorm_stats", a.ptr, a.n, a.hw, a.c, a.ld, groups, _f32c(weight, "gn weight").data_ptr(),
-           _f32c(bias, "gn bias").data_ptr(), float(eps), ss.data_ptr(), ws.data_ptr(), st)
     y = new_act(a.n, a.h, a.w, a.c, dev)
-    L.call("sdmi_groupnorm_apply", a.ptr, a.ld, ss.data_ptr(), y.ptr, y.ld, a.n, a.hw, a.c, L.F_SILU if silu else 0, st)
+    L.call("sdmi_groupnorm", a.ptr, a.ld, y.ptr, y.ld, a.n, a.hw, a.c, groups, _f32c(weight, "gn weight").data_ptr(),
+           _f32c(bias, "gn bias").data_ptr(), float(eps), L.F_SILU if silu else 0, ss.data_ptr(), ws.data_ptr(), _stream())
     return y
 
 

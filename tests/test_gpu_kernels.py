@@ -119,8 +119,10 @@ def test_conv3x3_in(cin, cout):
     _check(E.to_nchw(a), ref, 1.5e-3, 6e-4, "conv_in %d->%d" % (cin, cout))
 
 
-@pytest.mark.parametrize("c,hw,silu,eps", [(320, (12, 12), True, 1e-5), (64, (5, 7), False, 1e-6), (1920, (6, 6), True, 1e-5), (128, (40, 40), True, 1e-6), (2560, (3, 3), True, 1e-5)])
+@pytest.mark.parametrize("c,hw,silu,eps", [(320, (12, 12), True, 1e-5), (64, (5, 7), False, 1e-6), (1920, (6, 6), True, 1e-5), (128, (40, 40), True, 1e-6), (2560, (3, 3), True, 1e-5),
+                                            (320, (128, 128), True, 1e-5), (640, (48, 48), True, 1e-5), (320, (96, 96), False, 1e-6)])
 def test_groupnorm(c, hw, silu, eps):
+    """Small (sample, group) slices run the fused single-launch kernel, (320, 128x128) the stats + apply pair."""
     rs = _rs(c)
     x = _bf(_t(rs.randn(2, c, *hw) * 2 + 0.5))
     g, b = _t(1 + 0.1 * rs.randn(c)), _t(0.1 * rs.randn(c))
