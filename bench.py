@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pmc-workload", action="store_true",
+                    help="only run one eager UNet step + one decode (after a warm-up pass of both): the workload of the rocprofv3 --pmc passes behind roofline.traffic (profiles/README.md)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +133,16 @@ def main():
     noises = [g(n) for n in inp["noises"]]
     sampler = Sampler(unet, vae)
     total = b * world
+
+    if args.pmc_workload:
+        xc = torch.randn((2 * b, 9, L, L), device=dev)
+        tb = torch.full((2 * b,), 501, dtype=torch.long, device=dev)
+        cc = unet.precompute_context(torch.cat([uncond, cond]))
+        for _ in range(2):   # pass 1 warms up (weight pre-pack); pass 2 is the one profiles/pmc_traffic.py reads
+            unet(xc, timesteps=tb, context=cc)
+            vae.decode(x_T / 0.18215)
+            torch.cuda.synchronize()
+        return
 
     def one_step():
         _, img = sampler.sample(args.ddim_steps, cond, uncond, c_concat, x_T, noises, args.scale, use_graph=not args.no_graph)
@@ -175,6 +187,19 @@ def main():
     dec_ms = e0.elapsed_time(e1)
 
     roof, kernels = None, None
+    traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    pmc_traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+
+    def traffic_of(kernel):
+        """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md
+        HBM section), weighted like `achieved`: ddim_steps x the UNet-step launches + the decode launches."""
+        e = pmc_traffic.get("kernels", {}).get(kernel)
+        if not e or pmc_traffic.get("resolution") != args.res:
+            return None
+        byt = args.ddim_steps * e["unet"]["bytes"] + e["decode"]["bytes"]
+        n = args.ddim_steps * e["unet"]["launches"] + e["decode"]["launches"]
+        return byt / n if n else None
+
     if rank == 0 and not args.no_roofline:
         # dominant kernel: every C-ABI launch of one eager UNet step + one decode bracketed by HIP events on its stream
         with _lib.KernelTimer(work_of) as kt:
@@ -193,12 +218,12 @@ def main():
         if d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": d["ms"] / d["launches"],
+                    "frac": ach / PEAK_MFMA_TFLOPS, "traffic": traffic_of(dom), "avg_launch_ms": d["ms"] / d["launches"],
                     "launches_per_image": d["launches"], "share_of_image_time": d["ms"] / sum(v["ms"] for v in tot.values())}
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": d["ms"] / d["launches"],
+                    "frac": ach / PEAK_HBM_GBS, "traffic": traffic_of(dom), "avg_launch_ms": d["ms"] / d["launches"],
                     "launches_per_image": d["launches"], "share_of_image_time": d["ms"] / sum(v["ms"] for v in tot.values())}
         kernels = {k: {"ms_per_image": round(v["ms"], 3), "launches": v["launches"],
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,

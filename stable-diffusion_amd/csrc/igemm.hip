@@ -35,6 +35,7 @@ struct IgemmParams {
   int splits, kt_per_split, npad;
   float* ws;
   unsigned* ticket;  // split-K: per-tile arrival counters (in-kernel reduction by the last arriver); null = reduce kernel
+  int nmajor;    // tile order: consecutive tile ids walk M first (an XCD's run of tiles shares weight panels)
   int fast_epi;  // host-checked: shapes / alignments allow the LDS-transposed 16-byte epilogue
 };
 
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv / WN, wc = wv % WN, l15 = lane & 15, lq = lane >> 4;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int brow = (bid / tiles_n) * BM, bcol = (bid % tiles_n) * BN;
+  const int brow = (p.nmajor ? bid % tiles_m : bid / tiles_n) * BM, bcol = (p.nmajor ? bid / tiles_m : bid % tiles_n) * BN;
   const int bz = blockIdx.y;
   const u16* A = p.a + (long long)bz * p.sa;
   const u16* Wp = p.w + (long long)bz * p.sw;
@@ -720,6 +721,14 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     if (fl & SDMI_F_ROWBIAS) fast = fast && al16(p.rowbias) && p.ldrb % 4 == 0 && p.rows_per_sample >= bm;
     if (fl & SDMI_F_RESIDUAL) fast = fast && al16(p.res) && p.ldr % 8 == 0;
     p.fast_epi = fast ? 1 : 0;
+  }
+  // the XCD remap gives every XCD (private L2) a contiguous run of tile ids: order the ids so that the run shares the
+  // LARGER operand's panels - weight panels when N > M (the 24x24 / 12x12 levels: 29-59 MB of weights against 1-3 MB of
+  // activations), activation panels otherwise.  SDMI_NMAJOR=0/1 forces it (A/B switch).
+  {
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("SDMI_NMAJOR"); force = e ? atoi(e) : -1; }
+    p.nmajor = force >= 0 ? force : (p.N > p.M ? 1 : 0);
   }
   p.ticket = nullptr;
   // Opt-in (SDMI_SPLITK_INKERNEL=1): bit-identical to the reduce kernel, but measured SLOWER on the UNet step (10.9 ms
