@@ -40,7 +40,7 @@ DECODE_GFLOP = {64: 2514.5, 96: 5754.3, 128: 10470.4}
 def work_of(name, a):
     """(algorithmic flops, algorithmic bytes) of one C-ABI call from its arguments (see include/sdmi.h).  `name` is the
     kernel symbol for conv/gemm/attention calls (sdmi_last_kernel), the entry point otherwise."""
-    if name.startswith("igemm_kernel") and "true," in name:
+    if name.startswith("conv_win_kernel") or (name.startswith("igemm_kernel") and "true," in name):
         n, cin, cout, ho, wo = a[2], a[5], a[7], a[8], a[9]
         return 2.0 * n * ho * wo * cout * 9 * cin, 2.0 * (n * a[3] * a[4] * cin + n * ho * wo * cout + 9 * cin * cout)
     if name.startswith("igemm_kernel"):

@@ -13,7 +13,7 @@ for path in sys.argv[1:]:
     # group: each shape = 3 x (igemm [+ reduce]); walk sequentially
     ig=[]; cur=None
     for x in r:
-        if 'igemm_kernel' in x[0]:
+        if 'igemm_kernel' in x[0] or 'conv_win_kernel' in x[0]:
             cur=[x[0],x[1],x[3],x[4]]; ig.append(cur)
         elif 'splitk_reduce' in x[0] and cur is not None:
             cur[3]+=x[4]

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "sdmi_gemm": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp, _i64, _vp]),
     "sdmi_gemm_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _u32]),
     "sdmi_tune_override": (None, [_i, _i]),
+    "sdmi_tune_conv_window": (None, [_i]),
     "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
     "sdmi_timestep_embedding": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),

@@ -299,6 +299,109 @@ __device__ __forceinline__ void epi_finish(const IgemmParams& p, const EpiRegs<T
   }
 }
 
+// Everything after the K loop, shared by the GEMM / generic-conv kernel and the shared-window conv kernel: split-K partials
+// (+ optional in-launch reduction) and the epilogue.  row0 / col0 = first output row / column of this wave's tile.
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void igemm_finish(const IgemmParams& p, f32x4 (&acc)[TM / 16][TN / 16],
+                                             EpiRegs<TM, (!GEGLU || TN >= 64) ? TN : 64, GEGLU>& er, bool fast, u16* smem, int bz,
+                                             int row0, int col0) {
+  constexpr int MT = TM / 16, NT = TN / 16;
+  constexpr bool FAST_OK = !GEGLU || TN >= 64;
+  const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, lq = lane >> 4;
+  // ---- epilogue: lane holds out[m][n0..n0+3], m = tile row l15, n0 = 4*lq within each 16x16 tile ----
+  const uint32_t fl = p.flags;
+  if (p.splits > 1) {
+    // split-K: every block leaves its fp32 partial tile in the workspace; the block that draws the tile's last ticket
+    // sums all of them in split order (same bits whoever is last) and runs the epilogue.  Hand-off = write-through
+    // (sc1) stores, every wave drained, the ticket, one agent-scope acquire in the reducing block.
+    float* wsb = p.ws + ((long long)blockIdx.z * gridDim.y + bz) * p.M * p.npad;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = row0 + i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n0 = col0 + j * 16 + lq * 4;
+        if (n0 < p.npad) {
+          float* dst = wsb + (long long)m * p.npad + n0;
+          if (p.ticket)  // write-through (sc1) store: visible to the reducing block without an L2 write-back fence
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+          else
+            *(f32x4*)dst = acc[i][j];
+        }
+      }
+    }
+    if (!p.ticket) return;  // igemm_splitk_reduce_kernel finishes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // all partial stores issued and drained; every wave's trailing DMA has landed, the LDS is free
+    int* flag = (int*)smem;
+    if (t == 0) {
+      unsigned* tk = p.ticket + ((long long)bz * gridDim.x + blockIdx.x);
+      const unsigned prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == (unsigned)p.splits - 1u;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next call
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if constexpr (FAST_OK) if (fast) epi_prefetch<TM, TN, GEGLU>(p, er, bz, row0, col0, lane);
+    const long long per_split = (long long)gridDim.y * p.M * p.npad;
+    const float* base = p.ws + (long long)bz * p.M * p.npad;
+    for (int s = 0; s < p.splits; ++s) {
+      const float* sb = base + s * per_split;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = min(row0 + i * 16 + l15, p.M - 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n0 = min(col0 + j * 16 + lq * 4, p.npad - 4);
+          const f32x4 v = *(const f32x4*)(sb + (long long)m * p.npad + n0);
+          acc[i][j] = s == 0 ? v : acc[i][j] + v;
+        }
+      }
+    }
+  }
+  if constexpr (FAST_OK) if (fast) {
+    epi_finish<TM, TN, GEGLU>(p, er, acc, bz, row0, col0, lane);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = row0 + i * 16 + l15;
+    if (m >= p.M) continue;
+    if constexpr (GEGLU) {
+      const int half = p.N >> 1;
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int nb0 = col0 + j * 16;
+        if (nb0 >= p.N) continue;
+        const int oc = (nb0 >> 5) * 16 + lq * 4;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xv = acc[i][j][e] * p.alpha, gv = acc[i][j + 1][e] * p.alpha;
+          if (fl & SDMI_F_BIAS) { xv += p.bias[oc + e]; gv += p.bias[half + oc + e]; }
+          y[e] = xv * gelu_erf(gv);
+        }
+        u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + oc;
+        *(uint2*)o = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n0 = col0 + j * 16 + lq * 4;
+        if (n0 >= p.N) continue;
+        float y[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        epilogue4(p, bz, m, n0, y);
+      }
+    }
+  }
+}
+
 // The second launch bound (2 waves per SIMD for the 4-wave tiles = the 256-register budget they run at anyway) matters:
 // with the default 512-register budget hipcc split the accumulators over VGPRs and AGPRs and shuffled them with 74
 // v_accvgpr moves per K-tile in the plain-GEMM instantiations (MFMA not accumulating in place).
@@ -496,98 +599,184 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 #undef IGEMM_WAIT_STAGE
 #undef IGEMM_GLDS
 
-  // ---- epilogue: lane holds out[m][n0..n0+3], m = tile row l15, n0 = 4*lq within each 16x16 tile ----
-  const uint32_t fl = p.flags;
-  if (p.splits > 1) {
-    // split-K: every block leaves its fp32 partial tile in the workspace; the block that draws the tile's last ticket
-    // sums all of them in split order (same bits whoever is last) and runs the epilogue.  Hand-off = write-through
-    // (sc1) stores, every wave drained, the ticket, one agent-scope acquire in the reducing block.
-    float* wsb = p.ws + ((long long)blockIdx.z * gridDim.y + bz) * p.M * p.npad;
+  igemm_finish<TM, TN, GEGLU>(p, acc, er, fast, smem, bz, brow + wr * TM, bcol + wc * TN);
+}
+
+// ------------------------------------------------------------------------------------------ shared-window 3x3 conv
+// Stride-1, pad-1 convolutions.  The generic kernel stages a fresh 128 x 64 activation tile for each of the 9 taps; the
+// three taps of one kernel row (kx = 0, 1, 2) read the SAME pixels shifted by one, so here ONE window of BM + 2 pixel
+// rows is staged per (64-channel chunk, ky) and the three kx taps read it at row offsets 0 / 1 / 2: the activation
+// bytes that go through the L2 -> LDS path (what bounds these kernels, see the file header) drop 3x, all staged bytes
+// 1.5x.  Vertical padding is decided when a window row is staged (zero page), horizontal padding when a fragment is
+// read: lanes whose (pixel, kx) falls off the image row read a row of zeros kept behind each window buffer (the offset
+// is precomputed per lane, no work in the loop).  K-tile order (chunk, ky, kx) and all arithmetic are those of the
+// generic kernel, so both produce the same bits.  4 waves (2 x 2), two window buffers + a two-slot weight ring:
+// 66 KB (BN = 128) or 50 KB (BN = 64) of LDS, 2 - 3 blocks per CU.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_win_kernel(const IgemmParams p) {
+  constexpr int TM = BM / 2, TN = BN / 2, MT = TM / 16, NT = TN / 16;
+  constexpr int WROWS = BM + 8;           // staged window rows: BM + 2 are read; whole 8-row DMA instructions
+  constexpr int WBUF = (WROWS + 1) * BK;  // elements per window buffer, + one row of zeros
+  constexpr int BSLOT = BN * BK;
+  constexpr int PW = (WROWS + 31) / 32, PB = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];  // [2][WBUF] windows | [2][BSLOT] weight ring
+  u16* const bring = smem + 2 * WBUF;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1, l15 = lane & 15, lq = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int brow = (p.nmajor ? bid % tiles_m : bid / tiles_n) * BM, bcol = (p.nmajor ? bid / tiles_m : bid % tiles_n) * BN;
+  const u16* const zp = (const u16*)g_zero16;
+  const int hw = p.H * p.W;
+
+  if (t < 16) *(u32x4*)(smem + (t >> 3) * WBUF + WROWS * BK + (t & 7) * 8) = u32x4{0u, 0u, 0u, 0u};  // the zero rows
+
+  // ---- staging bookkeeping (fixed over the K loop) ----
+  const int r0 = t >> 3;
+  const int lchunk = (t & 7) ^ ((r0 >> 1) & 7);  // logical 16-B chunk this lane fetches (swizzle on the source side)
+  const int wave_row0 = __builtin_amdgcn_readfirstlane(wv) * 8;
+  const u16* w_ptr[PW];
+  int w_mask[PW];  // bit ky: window row readable for kernel row ky
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = brow + wr * TM + i * 16 + l15;
-      if (m >= p.M) continue;
+  for (int i = 0; i < PW; ++i) {
+    const int r = r0 + 32 * i, q = brow - 1 + r;  // window row r holds pixel q (flat N*H*W index)
+    const bool ok = r < WROWS && q >= 0 && q < p.M;
+    const int qc = ok ? q : 0;
+    const int img = qc / hw, y = (qc - img * hw) / p.W;
+    w_mask[i] = ok ? ((y >= 1 ? 1 : 0) | 2 | (y <= p.H - 2 ? 4 : 0)) : 0;
+    w_ptr[i] = p.a + (long long)qc * p.lda + lchunk * 8;
+  }
+  bool b_ok[PB];
+  const u16* b_ptr[PB];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n0 = bcol + wc * TN + j * 16 + lq * 4;
-        if (n0 < p.npad) {
-          float* dst = wsb + (long long)m * p.npad + n0;
-          if (p.ticket)  // write-through (sc1) store: visible to the reducing block without an L2 write-back fence
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
-          else
-            *(f32x4*)dst = acc[i][j];
-        }
-      }
-    }
-    if (!p.ticket) return;  // igemm_splitk_reduce_kernel finishes
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // all partial stores issued and drained; every wave's trailing DMA has landed, the LDS is free
-    int* flag = (int*)smem;
-    if (t == 0) {
-      unsigned* tk = p.ticket + ((long long)bz * gridDim.x + blockIdx.x);
-      const unsigned prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = prev == (unsigned)p.splits - 1u;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next call
-      }
-      *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return;
-    if constexpr (FAST_OK) if (fast) epi_prefetch<TM, TN, GEGLU>(p, er, bz, brow + wr * TM, bcol + wc * TN, lane);
-    const long long per_split = (long long)gridDim.y * p.M * p.npad;
-    const float* base = p.ws + (long long)bz * p.M * p.npad;
-    for (int s = 0; s < p.splits; ++s) {
-      const float* sb = base + s * per_split;
+  for (int i = 0; i < PB; ++i) {
+    const int gn = bcol + r0 + 32 * i;
+    b_ok[i] = gn < p.N;
+    b_ptr[i] = p.w + (long long)(b_ok[i] ? gn : 0) * p.ldw + lchunk * 8;
+  }
+  const int k_lim = p.Cin - lchunk * 8;  // this lane's chunk lies inside Cin iff (chunk base channel) < k_lim
+
+  // ---- fragment read offsets: window row = tile row + kx; off-row taps read the zero row ----
+  int aoff[MT][3];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = min(brow + wr * TM + i * 16 + l15, p.M - 1);
+  for (int mi = 0; mi < MT; ++mi) {
+    const int i = wr * TM + mi * 16 + l15, pix = brow + i;
+    const bool pv = pix < p.M;
+    const int pc = pv ? pix : 0;
+    const int x = (pc % hw) % p.W;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n0 = min(bcol + wc * TN + j * 16 + lq * 4, p.npad - 4);
-          const f32x4 v = *(const f32x4*)(sb + (long long)m * p.npad + n0);
-          acc[i][j] = s == 0 ? v : acc[i][j] + v;
-        }
-      }
+    for (int kx = 0; kx < 3; ++kx) {
+      const bool valid = pv && x + kx - 1 >= 0 && x + kx - 1 < p.W;
+      aoff[mi][kx] = valid ? lds_off(i + kx, lq) : WROWS * BK + lq * 8;
     }
   }
-  if constexpr (FAST_OK) if (fast) {
-    epi_finish<TM, TN, GEGLU>(p, er, acc, bz, brow + wr * TM, bcol + wc * TN, lane);
-    return;
+  int boff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) boff[j] = lds_off(wc * TN + j * 16 + l15, lq);
+
+  const int kt_begin = blockIdx.z * p.kt_per_split;          // multiples of 3 (host)
+  const int kt_end = min(p.nk, kt_begin + p.kt_per_split);
+  int s_cb = kt_begin / 9, s_tap = kt_begin - s_cb * 9, s_kt = kt_begin;  // next weight tile to stage
+  int w_cb = s_cb, w_ky = s_tap / 3;                                        // next window to stage
+
+#define WIN_GLDS(SRC, DST) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+#define WIN_STAGE_W(WB)                                                                                   \
+  {                                                                                                       \
+    const int c0 = w_cb * BK;                                                                             \
+    const bool cok = c0 < k_lim;                                                                          \
+    const long long koff = (long long)(w_ky - 1) * p.W * p.lda + c0;                                      \
+    _Pragma("unroll") for (int i = 0; i < PW; ++i) {                                                      \
+      if (wave_row0 + 32 * i < WROWS) {                                                                   \
+        const u16* src = (((w_mask[i] >> w_ky) & 1) && cok) ? w_ptr[i] + koff : zp;                       \
+        WIN_GLDS(src, (WB) + (wave_row0 + 32 * i) * BK);                                                  \
+      }                                                                                                   \
+    }                                                                                                     \
+    if (++w_ky == 3) { w_ky = 0; ++w_cb; }                                                                \
   }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = brow + wr * TM + i * 16 + l15;
-    if (m >= p.M) continue;
-    if constexpr (GEGLU) {
-      const int half = p.N >> 1;
-#pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        const int nb0 = bcol + wc * TN + j * 16;
-        if (nb0 >= p.N) continue;
-        const int oc = (nb0 >> 5) * 16 + lq * 4;
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float xv = acc[i][j][e] * p.alpha, gv = acc[i][j + 1][e] * p.alpha;
-          if (fl & SDMI_F_BIAS) { xv += p.bias[oc + e]; gv += p.bias[half + oc + e]; }
-          y[e] = xv * gelu_erf(gv);
-        }
-        u16* o = (u16*)p.out + (long long)bz * p.sc + (long long)m * p.ldc + oc;
-        *(uint2*)o = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n0 = bcol + wc * TN + j * 16 + lq * 4;
-        if (n0 >= p.N) continue;
-        float y[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        epilogue4(p, bz, m, n0, y);
-      }
-    }
+#define WIN_STAGE_B(SLOT)                                                                                 \
+  if (s_kt < kt_end) {                                                                                    \
+    const int c0 = s_cb * BK;                                                                             \
+    const bool cok = c0 < k_lim;                                                                          \
+    const int wk = s_tap * p.Cin + c0;                                                                    \
+    u16* dB = bring + (SLOT) * BSLOT + wave_row0 * BK;                                                    \
+    _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                      \
+      const u16* src = (b_ok[i] && cok) ? b_ptr[i] + wk : zp;                                             \
+      WIN_GLDS(src, dB + i * 32 * BK);                                                                    \
+    }                                                                                                     \
+    ++s_kt;                                                                                               \
+    if (++s_tap == 9) { s_tap = 0; ++s_cb; }                                                              \
   }
+#define WIN_WAIT()                                                \
+  {                                                               \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                                 \
+  }
+#define WIN_READ(AF, WF, WB, KX, KK, SLOT)                                                                          \
+  {                                                                                                                 \
+    const u16* cB = bring + (SLOT) * BSLOT;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) AF[i] = *(const hx8*)&(WB)[aoff[i][KX] ^ ((KK) ? 32 : 0)];       \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const hx8*)&cB[boff[j] ^ ((KK) ? 32 : 0)];             \
+  }
+#define WIN_MFMA(AF, WF)                                                                                   \
+  {                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(WF[j], AF[i], acc[i][j], 0, 0, 0); \
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  hx8 af0[MT], wf0[NT], af1[MT], wf1[NT];
+  EpiRegs<TM, TN, false> er;
+  const bool fast = p.fast_epi;
+  if (fast && p.splits == 1) epi_prefetch<TM, TN, false>(p, er, 0, brow + wr * TM, bcol + wc * TN, lane);
+
+  WIN_STAGE_W(smem);
+  WIN_STAGE_B(0);
+  WIN_STAGE_B(1);
+  WIN_WAIT();
+  WIN_READ(af0, wf0, smem, 0, 0, 0);
+  int slot = 0, wsel = 0;
+  for (int kt = kt_begin; kt < kt_end; kt += 3) {
+    const u16* wcur = smem + wsel * WBUF;
+    u16* wnext = smem + (wsel ^ 1) * WBUF;
+    // kx = 0
+    WIN_READ(af1, wf1, wcur, 0, 1, slot);
+    WIN_MFMA(af0, wf0);
+    WIN_WAIT();
+    WIN_STAGE_B(slot);
+    if (kt + 3 < kt_end) WIN_STAGE_W(wnext);
+    slot ^= 1;
+    WIN_READ(af0, wf0, wcur, 1, 0, slot);
+    WIN_MFMA(af1, wf1);
+    // kx = 1
+    WIN_READ(af1, wf1, wcur, 1, 1, slot);
+    WIN_MFMA(af0, wf0);
+    WIN_WAIT();
+    WIN_STAGE_B(slot);
+    slot ^= 1;
+    WIN_READ(af0, wf0, wcur, 2, 0, slot);
+    WIN_MFMA(af1, wf1);
+    // kx = 2
+    WIN_READ(af1, wf1, wcur, 2, 1, slot);
+    WIN_MFMA(af0, wf0);
+    WIN_WAIT();
+    WIN_STAGE_B(slot);
+    slot ^= 1;
+    WIN_READ(af0, wf0, wnext, 0, 0, slot);  // first tile of the next (chunk, ky); unused after the last one
+    WIN_MFMA(af1, wf1);
+    wsel ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef WIN_GLDS
+#undef WIN_STAGE_W
+#undef WIN_STAGE_B
+#undef WIN_WAIT
+#undef WIN_READ
+#undef WIN_MFMA
+  igemm_finish<TM, TN, false>(p, acc, er, fast, smem, 0, brow + wr * TM, bcol + wc * TN);
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -595,8 +784,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 // produces the same bits whether it runs alone or inside a larger batch (the image-sharded multi-GPU path relies on
 // it).  Under-filled grids (few output tiles, long K) are cut so that >= ~384 blocks exist per sample.
 // tuning override (sdmi_tune_override): -1 = automatic
-static int g_force_tile = -1, g_force_splits = -1;
+static int g_force_tile = -1, g_force_splits = -1, g_force_window = -1;
 extern "C" void sdmi_tune_override(int tile, int splits) { g_force_tile = tile; g_force_splits = splits; }
+extern "C" void sdmi_tune_conv_window(int on) { g_force_window = on; }
 
 static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags, bool conv) {
   if (flags & SDMI_F_GEGLU) return 1;
@@ -705,6 +895,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   const int s = splitk_factor(p.rows_per_sample, p.N, p.nk, p.flags, CONV);
   if (s >= 2 && ws && ws_bytes >= splitk_ws_bytes(p.M, p.N, p.nk, batch, p.rows_per_sample, p.flags, CONV)) {
     p.kt_per_split = (p.nk + s - 1) / s;
+    if (CONV) p.kt_per_split = (p.kt_per_split + 2) / 3 * 3;  // whole (chunk, ky) groups: the shared-window kernel needs it
     p.splits = (p.nk + p.kt_per_split - 1) / p.kt_per_split;
     p.ws = (float*)ws;
   }
@@ -748,6 +939,35 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     p.ticket = (unsigned*)sym + (((uintptr_t)ws >> 8) % SK_TICKET_BANKS) * SK_TICKET_TILES;
   }
   dim3 grid(nb, batch, p.splits);
+  if constexpr (CONV) {
+    // stride-1 pad-1 convs on 128-row tiles: the shared-window kernel (SDMI_CONV_WIN=0 keeps the generic one: A/B switch)
+    static int win_env = -1;
+    if (win_env < 0) { const char* e = getenv("SDMI_CONV_WIN"); win_env = (e && e[0] == '0') ? 0 : 1; }
+    const int win_ok = g_force_window >= 0 ? g_force_window : win_env;
+    if (win_ok && (vi == 1 || vi == 2) && p.stride == 1 && !p.ups && p.pad_t == 1 && p.pad_l == 1 && p.Ho == p.H && p.Wo == p.W && batch == 1) {
+      constexpr int wbytes128 = (2 * (128 + 8 + 1) * BK + 2 * 128 * BK) * 2, wbytes64 = (2 * (128 + 8 + 1) * BK + 2 * 64 * BK) * 2;
+      if (vi == 1) {
+        static unsigned long long attr_done = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((attr_done >> (dev & 63)) & 1ull)) {
+          (void)hipFuncSetAttribute((const void*)conv_win_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
+          attr_done |= 1ull << (dev & 63);
+        }
+        hipLaunchKernelGGL((conv_win_kernel<128, 128>), grid, dim3(256), wbytes128, st, p);
+      } else {
+        hipLaunchKernelGGL((conv_win_kernel<128, 64>), grid, dim3(256), wbytes64, st, p);
+      }
+      sdmi_note_kernel("conv_win_kernel<128, %d>%s", bn, (p.splits > 1 && !p.ticket) ? " + igemm_splitk_reduce_kernel" : "");
+      int rcw = sdmi_check_launch("conv3x3 (shared window)");
+      if (rcw || p.splits < 2 || p.ticket) return rcw;
+      long long items = (long long)batch * p.M * (p.npad / 4);
+      long long rb = (items + 255) / 256;
+      if (rb > 4096) rb = 4096;
+      hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
+      return sdmi_check_launch("split-K reduce");
+    }
+  }
   switch (vi) {
     case 0: launch_variant<256, 128, 4, 2, CONV, 3>(grid, st, p); break;
     case 1: launch_variant<128, 128, 2, 2, CONV, 2>(grid, st, p); break;

@@ -231,6 +231,36 @@ def test_conv_rowbias_tile_rows_past_m():
     _check(out, ref, 1.5e-3, 6e-4, "conv rowbias, rows past M")
 
 
+@pytest.mark.parametrize("tile,splits", [(1, 1), (2, 1), (1, 3), (2, 2)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 128, 16, 16), (1, 320, 192, 13, 9), (3, 72, 64, 7, 20), (2, 128, 320, 24, 24)])
+def test_conv_shared_window_kernel(n, cin, cout, h, w, tile, splits):
+    """The shared-window kernel (128-row tiles, stride 1): parity against torch, and the SAME bits as the generic im2col
+    kernel on the same tile / split (same K order, same arithmetic).  Shapes: rows that wrap image rows inside a tile,
+    M not a multiple of 128, images that end inside a tile, Cin with a partial 64-channel chunk, 5 chunks."""
+    rs = _rs(n * cin + cout + h)
+    x = _bf(_t(rs.randn(n, cin, h, w)))
+    wt, b = _t(rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)), _t(rs.randn(cout))
+    temb, res = _t(rs.randn(n, cout)), _bf(_t(rs.randn(n, cout, h, w)))
+    ref = F.conv2d(x, _bf(wt), b, padding=1) + temb[:, :, None, None] + res
+    W, B, TE = torch.nn.Parameter(wt.to(DEV)), b.to(DEV), temb.to(DEV)
+    lib = L.load()
+    outs = {}
+    try:
+        for win in (1, 0):
+            lib.sdmi_tune_override(tile, splits)
+            lib.sdmi_tune_conv_window(win)
+            o = E.conv3x3(_act(x), W, B, rowbias=TE if h * w >= 128 else None, ldrb=cout, residual=_act(res))
+            outs[win] = (E.to_nchw(o), lib.sdmi_last_kernel().decode())
+    finally:
+        lib.sdmi_tune_override(-1, -1)
+        lib.sdmi_tune_conv_window(-1)
+    assert outs[1][1].startswith("conv_win_kernel") and outs[0][1].startswith("igemm_kernel"), (outs[1][1], outs[0][1])
+    if h * w < 128:
+        ref = ref - temb[:, :, None, None]
+    _check(outs[1][0], ref, 1.5e-3, 6e-4, "shared-window conv")
+    assert torch.equal(outs[1][0], outs[0][0]), "shared-window and generic kernels differ"
+
+
 def test_splitk_conv_and_gemm_batch_invariant():
     """Under-filled grids run split-K (fp32 partials + a fixed-order reduce): parity holds and one image gives the
     same bits alone or inside a batch (the split factor depends on the per-sample shape only)."""
