@@ -104,16 +104,17 @@ extern "C" int sdmi_pack_linear(const float* w, void* w_packed, int n, int k, in
 }
 
 // ------------------------------------------------------------------------------------ first conv (tiny Cin)
-// x NCHW fp32 (the caller's tensor), w OIHW fp32, out NHWC bf16.  thread = (pixel, 8 output channels); the
-// 9*CIN input taps sit in registers, weights are read through the scalar/L1 path (uniform per half-wave).
+// x NCHW fp32 (the caller's tensor), w OIHW fp32, out NHWC h16.  lane = pixel (64 consecutive pixels per wave: coalesced
+// NCHW reads), wave = group of 8 output channels: the weight index is wave-uniform, so the 8 x 9*CIN weights arrive
+// through scalar loads and every FMA takes its weight from an SGPR; the 9*CIN input taps sit in registers.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, u16* __restrict__ out, int h,
                                                          int wd, int cout, int ldc) {
   const int n = blockIdx.z;
   const int hw = h * wd;
-  const int pix = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int cg = blockIdx.y * 8 + (threadIdx.x >> 5);  // group of 8 output channels
+  const int pix = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int cg = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // group of 8 output channels (wave-uniform)
   if (pix >= hw || cg * 8 >= cout) return;
   const int oy = pix / wd, ox = pix - oy * wd;
   float in[CIN * 9];
@@ -146,7 +147,7 @@ extern "C" int sdmi_conv3x3_in(const float* x_nchw, int n, int cin, int h, int w
   SDMI_REQUIRE(x_nchw && w_oihw && bias && out, "conv3x3_in: null pointer");
   SDMI_REQUIRE(n > 0 && h > 0 && w > 0 && cout > 0 && n <= 65535, "conv3x3_in: bad shape");
   SDMI_REQUIRE(ldc % 8 == 0 && ldc >= cout && ((uintptr_t)out & 15) == 0, "conv3x3_in: ldc/alignment");
-  dim3 grid((h * w + 31) / 32, ((cout + 7) / 8 + 7) / 8, n), block(256);
+  dim3 grid((h * w + 63) / 64, ((cout + 7) / 8 + 3) / 4, n), block(256);
   hipStream_t st = (hipStream_t)stream;
   switch (cin) {
     case 3: hipLaunchKernelGGL(conv3x3_in_kernel<3>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc); break;

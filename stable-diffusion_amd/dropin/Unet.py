@@ -23,6 +23,14 @@ IN_CH, MODEL_CH, OUT_CH = 9, 320, 4
 RES_BLOCKS, ATTN_DS, CH_MULT, HEAD_CH = (2, 2, 2, 2), (1, 2, 4), (1, 2, 4, 4), 64
 
 
+class TimeEmb(object):
+    """Precomputed timestep-embedding table of one UNet evaluation (Unet.precompute_time_embedding)."""
+    __slots__ = ("table",)
+
+    def __init__(self, table):
+        self.table = table
+
+
 class Unet(nn.Module):
     def __init__(self):
         super().__init__()
@@ -92,11 +100,21 @@ class Unet(nn.Module):
         rbs = list(self._resblocks())
         w = E.packed_linear(tuple(rb.emb_proj.weight for rb in rbs))
         b = E.stacked_f32(tuple(rb.emb_proj.bias for rb in rbs))
-        allp = E.linear_small_m(t_emb, w, b, silu_in=True)          # (Bc, sum C_out)
+        return E.linear_small_m(t_emb, w, b, silu_in=True)          # (Bc, sum C_out)
+
+    @torch.no_grad()
+    def precompute_time_embedding(self, timesteps):
+        """time_embed MLP + every ResBlock's emb_proj for these timesteps, as one (Bc, sum C_out) fp32 table.  It depends on
+        t only, so a sampler computes it once per schedule step and passes it as `timesteps=` (step-invariant hoisting,
+        SURVEY 8(f)-3); forward() accepts either the LongTensor of the reference or this object."""
+        return TimeEmb(self._embeddings(timesteps))
+
+    def _emb_pointers(self, allp):
         offs, o = {}, 0
-        for rb in rbs:
+        for rb in self._resblocks():
             offs[id(rb)] = allp.data_ptr() + 4 * o
             o += rb.emb_proj.weight.shape[0]
+        assert o == allp.shape[1], "time-embedding table does not match this UNet"
         return allp, offs, allp.shape[1]
 
     @staticmethod
@@ -120,7 +138,7 @@ class Unet(nn.Module):
         x = x.contiguous().float()
         n, _, hh, ww = x.shape
         dev = x.device
-        keep, emb, ldrb = self._embeddings(timesteps)
+        keep, emb, ldrb = self._emb_pointers(timesteps.table if isinstance(timesteps, TimeEmb) else self._embeddings(timesteps))
         ctx = context if isinstance(context, ContextKV) else self.precompute_context(context)
 
         # ---- geometry + concat plan: skip k is consumed by output block (K-1-k) next to an `h` of cat_c1[k] channels

@@ -48,11 +48,37 @@ class Sampler(object):
         self.dual_stream = (os.environ.get("SDMI_DUAL_STREAM", "0") == "1") if dual_stream is None else bool(dual_stream)
         self._side = None
 
+    def _time_tables(self, steps, bc, dev):
+        w = self.unet.time_embed[0].weight
+        key = (tuple(int(s) for s in steps), bc, str(dev), w.data_ptr(), w._version)
+        if getattr(self, "_tt_key", None) != key:
+            t_buf = torch.empty((bc,), dtype=torch.long, device=dev)
+            rows = []
+            for s in steps:
+                t_buf.fill_(int(s))
+                rows.append(self.unet.precompute_time_embedding(t_buf).table)
+            self._tt, self._tt_key = torch.stack(rows).contiguous(), key
+        return self._tt
+
+    def _emb_static(self, table, dev):
+        from Unet import TimeEmb
+        cur = getattr(self, "_emb_cur", None)
+        if cur is None or cur.table.shape != table.shape[1:] or cur.table.device != table.device:
+            self._emb_cur = cur = TimeEmb(torch.empty_like(table[0]))
+        return cur
+
     def make_context(self, uncond, cond):
         """Step-invariant text-context K/V of the CFG batch [uncond | cond] (one object per half when dual_stream)."""
         if self.dual_stream:
             return (self.unet.precompute_context(uncond.contiguous()), self.unet.precompute_context(cond.contiguous()))
         return self.unet.precompute_context(torch.cat([uncond, cond]).contiguous())
+
+    @staticmethod
+    def _half(t_buf, b, which):
+        if hasattr(t_buf, "table"):
+            from Unet import TimeEmb
+            return TimeEmb(t_buf.table[which * b:(which + 1) * b])
+        return t_buf[which * b:(which + 1) * b]
 
     def _unet_eval(self, xc, t_buf, cc):
         if not self.dual_stream:
@@ -61,14 +87,14 @@ class Sampler(object):
         cur = torch.cuda.current_stream()
         if self._side is None:
             # first use: one pass on the current stream fills the weight pre-pack cache (shared by both streams)
-            self.unet(xc[:b], timesteps=t_buf[:b], context=cc[0])
+            self.unet(xc[:b], timesteps=self._half(t_buf, b, 0), context=cc[0])
             torch.cuda.synchronize()
             self._side = torch.cuda.Stream()
         side = self._side
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            e1 = self.unet(xc[b:], timesteps=t_buf[b:], context=cc[1])
-        e0 = self.unet(xc[:b], timesteps=t_buf[:b], context=cc[0])
+            e1 = self.unet(xc[b:], timesteps=self._half(t_buf, b, 1), context=cc[1])
+        e0 = self.unet(xc[:b], timesteps=self._half(t_buf, b, 0), context=cc[0])
         cur.wait_stream(side)
         return torch.cat([e0, e1])
 
@@ -76,7 +102,7 @@ class Sampler(object):
     def _unet_step(self, xc, t_buf, cc, use_graph):
         if not use_graph:
             return self._unet_eval(xc, t_buf, cc)
-        key = (xc.data_ptr(), t_buf.data_ptr(), id(cc), tuple(xc.shape))
+        key = (xc.data_ptr(), t_buf.table.data_ptr() if hasattr(t_buf, "table") else t_buf.data_ptr(), id(cc), tuple(xc.shape))
         if self._gkey != key:
             self._unet_eval(xc, t_buf, cc)                      # warm-up: weight pre-pack, allocator pools
             torch.cuda.synchronize()
@@ -103,12 +129,15 @@ class Sampler(object):
         xc[b:, 4:] = c_concat
         # text-context K/V projections do not depend on the step: project once per prompt
         cc = self.make_context(uncond, cond)
-        t_buf = torch.empty((2 * b,), dtype=torch.long, device=dev)
+        # the timestep-embedding MLPs depend on t only: one table per schedule step, computed once per schedule and kept
+        # across images; a step copies its row into the static buffer the (graph-captured) UNet reads
+        emb_table = self._time_tables(np.flip(ts), 2 * b, dev)
+        emb_cur = self._emb_static(emb_table, dev)
         x = x_T.clone()
         for i, step in enumerate(np.flip(ts)):
             index = total - i - 1
-            t_buf.fill_(int(step))
-            eps = self._unet_step(xc, t_buf, cc, use_graph)
+            emb_cur.table.copy_(emb_table[i])
+            eps = self._unet_step(xc, emb_cur, cc, use_graph)
             E.cfg_ddim_step(eps, x, noises[i], scale, _f32(s1m[index]), _f32(a_t[index]), _f32(a_prev[index]),
                             _f32(sig[index]), temperature, x_out=x, xc_out=xc)
             if trace is not None:
