@@ -1,0 +1,24 @@
+import sys, time, torch
+sys.path.insert(0, ".")
+import stable_diffusion_amd
+from stable_diffusion_amd import engine as E
+dev = "cuda"; H = E.act_dtype()
+def timed(g, reps, iters=5):
+    g.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters): g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters / reps * 1e6
+for (b, heads, nq, nkv) in [(2, 5, 9216, 9216), (2, 10, 2304, 2304), (2, 20, 576, 576), (2, 5, 9216, 77), (2, 10, 2304, 77)]:
+    c = heads * 64
+    q = E.Act(torch.randn(b, nq, c, device=dev).to(H), b, 1, nq, c)
+    k = E.Act(torch.randn(b, nkv, c, device=dev).to(H), b, 1, nkv, c)
+    v = E.Act(torch.randn(b, nkv, c, device=dev).to(H), b, 1, nkv, c)
+    o = E.new_act(b, 1, nq, c, dev)
+    fn = lambda: E.attention(q, k, v, heads, out=o)
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10): fn()
+    t = timed(g, 10)
+    print("attention b=%d heads=%d nq=%d nkv=%d: %7.1f us  %6.0f TF" % (b, heads, nq, nkv, t, 4.0 * b * heads * nq * nkv * 64 / t / 1e6), flush=True)

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdmi355.so")
+LIB_PATH = os.environ.get("SDMI_LIB_PATH") or os.path.join(_HERE, "libsdmi355.so")   # env: A/B another build of the library
 
 # flags (sdmi.h)
 F_BIAS, F_ROWBIAS, F_RESIDUAL, F_GEGLU, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_SILU, F_OUT_F32 = 1, 2, 4, 8, 16, 32, 64, 128

@@ -22,13 +22,12 @@ struct AttnParams {
   float scale_log2;
 };
 
-__device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4] = {0u, 0u, 0u, 0u};
-
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 1) << 2)) << 3); }
 
 // One KV tile for one wave: S^T = K Q^T, online softmax with the query on the lane, O^T += V^T P^T.
-__device__ __forceinline__ void attn_tile(bool tail, const u16* sK, const u16* sV, const hx8 (&qf)[4], f32x16 (&oacc)[2], float& mrun,
+template <bool TAIL>
+__device__ __forceinline__ void attn_tile(const u16* sK, const u16* sV, const hx8 (&qf)[4], f32x16 (&oacc)[2], float& mrun,
                                           float& lrun, float scale_log2, int kv0, int nkv, int r, int hh, int dblk, int tq,
                                           int tp) {
   f32x16 s[2];
@@ -41,8 +40,10 @@ __device__ __forceinline__ void attn_tile(bool tail, const u16* sK, const u16* s
       const hx8 a = *(const hx8*)&sK[k_off(32 * kt2 + r, 2 * ks + hh)];
       s[kt2] = MFMA32(a, qf[ks], s[kt2], 0, 0, 0);
     }
-  // raw-score max (scale > 0, so max commutes with the scaling); padded keys of the last tile are excluded
-  if (__builtin_amdgcn_readfirstlane((int)tail)) {  // wave-uniform: only the last, partial tile pays for the masking
+  // raw-score max (scale > 0, so max commutes with the scaling); padded keys of the last tile are excluded.  TAIL is a
+  // template parameter and the partial tile is peeled out of the loop: as a run-time (even wave-uniform) condition hipcc
+  // turned the mask into ~100 always-executed compare/select instructions per tile, a third of the loop's VALU work.
+  if constexpr (TAIL) {
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
@@ -58,8 +59,9 @@ __device__ __forceinline__ void attn_tile(bool tail, const u16* sK, const u16* s
     for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kt2][i]);
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   const float mnew = fmaxf(mrun, mx * scale_log2);
-  const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-  mrun = mnew;
+  // the running maximum settles after a few tiles: when no lane's maximum moved (wave-uniform test) alpha is exactly 1 for
+  // every lane and the rescale of O and l (17 VALU instructions per tile) is skipped
+  const bool moved = __builtin_amdgcn_ballot_w64(mnew > mrun) != 0;
   float rs = 0.f;
 #pragma unroll
   for (int kt2 = 0; kt2 < 2; ++kt2)
@@ -69,9 +71,14 @@ __device__ __forceinline__ void attn_tile(bool tail, const u16* sK, const u16* s
       s[kt2][i] = e;
       rs += e;
     }
-  lrun = lrun * alpha + rs;
+  if (moved) {
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+    lrun *= alpha;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+  }
+  lrun += rs;
+  mrun = mnew;
 #pragma unroll
   for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
@@ -98,8 +105,8 @@ __device__ __forceinline__ void attn_tile(bool tail, const u16* sK, const u16* s
 // grid: 1-D, nqt * heads * batch blocks; the XCD remap gives each XCD a contiguous run of (batch, head, q-tile) so
 // the K/V of the (one or two) heads an XCD is working on stay in its 4 MB L2 instead of being re-streamed by 8 XCDs.
 __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) u16 sK[64 * 64];
-  __shared__ __attribute__((aligned(16))) u16 sV[64 * 64];
+  __shared__ __attribute__((aligned(16))) u16 sK[2][64 * 64];  // double-buffered: one barrier per KV tile
+  __shared__ __attribute__((aligned(16))) u16 sV[2][64 * 64];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hh = lane >> 5;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = bid % p.nqt, bh = bid / p.nqt;
@@ -115,26 +122,32 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const hx8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
 
-  // staging: 64 rows x 8 chunks of 16 B per tile and operand; thread -> (row = t>>3 (+32), chunk = t&7).
-  // Keys past nkv read a 16-byte zero page (unconditional loads: they stay in flight across the MFMAs).
+  // staging: 64 rows x 8 chunks of 16 B per tile and operand; thread -> (row = t>>3 (+32), chunk = t&7).  Full tiles
+  // advance four per-thread pointers by a constant; the last, partial tile clamps its key rows to nkv-1 (those columns
+  // of S are masked to -inf, so the duplicated rows weigh nothing): no per-load predicates in the steady state.
   const int chunk = t & 7, r0 = t >> 3;
   u32x4 rk0, rk1, rv0, rv1;
-  const u16* const zp = (const u16*)g_attn_zero16;
+  const u16 *pk0 = K + (long long)r0 * p.ldk + chunk * 8, *pk1 = pk0 + (long long)32 * p.ldk;
+  const u16 *pv0 = V + (long long)r0 * p.ldv + chunk * 8, *pv1 = pv0 + (long long)32 * p.ldv;
+  const long long stepk = (long long)64 * p.ldk, stepv = (long long)64 * p.ldv;
 #define ATTN_LOAD_TILE(KV0)                                                                   \
-  {                                                                                           \
-    const int key0 = (KV0) + r0, key1 = (KV0) + r0 + 32;                                      \
-    const bool ok0 = key0 < p.nkv, ok1 = key1 < p.nkv;                                        \
-    rk0 = *(const u32x4*)(ok0 ? K + (long long)key0 * p.ldk + chunk * 8 : zp);                \
-    rv0 = *(const u32x4*)(ok0 ? V + (long long)key0 * p.ldv + chunk * 8 : zp);                \
-    rk1 = *(const u32x4*)(ok1 ? K + (long long)key1 * p.ldk + chunk * 8 : zp);                \
-    rv1 = *(const u32x4*)(ok1 ? V + (long long)key1 * p.ldv + chunk * 8 : zp);                \
+  if ((KV0) + 64 <= p.nkv) {                                                                  \
+    rk0 = *(const u32x4*)pk0; rv0 = *(const u32x4*)pv0;                                       \
+    rk1 = *(const u32x4*)pk1; rv1 = *(const u32x4*)pv1;                                       \
+    pk0 += stepk; pk1 += stepk; pv0 += stepv; pv1 += stepv;                                   \
+  } else {                                                                                    \
+    const int key0 = min((KV0) + r0, p.nkv - 1), key1 = min((KV0) + r0 + 32, p.nkv - 1);      \
+    rk0 = *(const u32x4*)(K + (long long)key0 * p.ldk + chunk * 8);                           \
+    rv0 = *(const u32x4*)(V + (long long)key0 * p.ldv + chunk * 8);                           \
+    rk1 = *(const u32x4*)(K + (long long)key1 * p.ldk + chunk * 8);                           \
+    rv1 = *(const u32x4*)(V + (long long)key1 * p.ldv + chunk * 8);                           \
   }
-#define ATTN_STORE_TILE()                                  \
-  {                                                        \
-    *(u32x4*)&sK[k_off(r0, chunk)] = rk0;                  \
-    *(u32x4*)&sV[v_off(r0, chunk)] = rv0;                  \
-    *(u32x4*)&sK[k_off(r0 + 32, chunk)] = rk1;             \
-    *(u32x4*)&sV[v_off(r0 + 32, chunk)] = rv1;             \
+#define ATTN_STORE_TILE(B)                                    \
+  {                                                           \
+    *(u32x4*)&sK[B][k_off(r0, chunk)] = rk0;                  \
+    *(u32x4*)&sV[B][v_off(r0, chunk)] = rv0;                  \
+    *(u32x4*)&sK[B][k_off(r0 + 32, chunk)] = rk1;             \
+    *(u32x4*)&sV[B][v_off(r0 + 32, chunk)] = rv1;             \
   }
 
   f32x16 oacc[2];
@@ -147,14 +160,19 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
 
   const int ntiles = (p.nkv + 63) / 64;
   ATTN_LOAD_TILE(0);
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int kv0 = tile * 64;
-    ATTN_STORE_TILE();
-    __syncthreads();
-    if (tile + 1 < ntiles) ATTN_LOAD_TILE(kv0 + 64);
-    attn_tile(kv0 + 64 > p.nkv, sK, sV, qf, oacc, mrun, lrun, p.scale_log2, kv0, p.nkv, r, hh, dblk, tq, tp);
+  ATTN_STORE_TILE(0);
+  __syncthreads();
+  const int nfull = p.nkv >> 6;  // full tiles run the mask-free instantiation
+  for (int tile = 0; tile < nfull; ++tile) {
+    const int kv0 = tile * 64, cur = tile & 1;
+    const bool more = tile + 1 < ntiles;
+    if (more) { ATTN_LOAD_TILE(kv0 + 64); }  // in flight over this tile's MFMAs
+    attn_tile<false>(sK[cur], sV[cur], qf, oacc, mrun, lrun, p.scale_log2, kv0, p.nkv, r, hh, dblk, tq, tp);
+    if (more) ATTN_STORE_TILE(cur ^ 1);  // the other buffer: last read in tile-1, every wave is past that barrier
     __syncthreads();
   }
+  if (nfull < ntiles)  // the partial last tile (already staged by the iteration before it, or by the prologue)
+    attn_tile<true>(sK[nfull & 1], sV[nfull & 1], qf, oacc, mrun, lrun, p.scale_log2, nfull * 64, p.nkv, r, hh, dblk, tq, tp);
 #undef ATTN_LOAD_TILE
 #undef ATTN_STORE_TILE
 
