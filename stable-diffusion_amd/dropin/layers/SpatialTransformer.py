@@ -20,15 +20,26 @@ class ContextKV(object):
     layers/SpatialTransformer.py:73-74).  `kv[id(attn_module)]` is that layer's (B, 77, 2*inner) view."""
 
     def __init__(self, attn_modules, context):
-        ctx = context if isinstance(context, E.Act) else E.tokens_from_f32(context)
-        ws = tuple(w for m in attn_modules for w in (m.to_k.weight, m.to_v.weight))
-        ntot = sum(w.shape[0] for w in ws)
-        allkv = E.gemm(ctx, E.packed_linear(ws), ntot)
+        self._modules = list(attn_modules)
+        self._ws = tuple(w for m in self._modules for w in (m.to_k.weight, m.to_v.weight))
+        self._ntot = sum(w.shape[0] for w in self._ws)
+        self._allkv = None
+        self.update(context)
         self.kv, off = {}, 0
-        for m in attn_modules:
+        for m in self._modules:
             n2 = m.to_k.weight.shape[0] + m.to_v.weight.shape[0]
-            self.kv[id(m)] = allkv.cols(off, n2)
+            self.kv[id(m)] = self._allkv.cols(off, n2)
             off += n2
+
+    def update(self, context):
+        """Project a new prompt INTO THE SAME BUFFERS (same batch and token count): a HIP graph captured over a forward
+        that read this object stays valid, which is how the sampler reuses one captured step across images."""
+        ctx = context if isinstance(context, E.Act) else E.tokens_from_f32(context)
+        if self._allkv is not None:
+            assert (ctx.n, ctx.h * ctx.w) == self._shape, "ContextKV.update: batch / token count changed"
+        self._shape = (ctx.n, ctx.h * ctx.w)
+        self._allkv = E.gemm(ctx, E.packed_linear(self._ws), self._ntot, out=self._allkv)
+        return self
 
 
 def _as_ctx(context):

@@ -68,10 +68,25 @@ class Sampler(object):
         return cur
 
     def make_context(self, uncond, cond):
-        """Step-invariant text-context K/V of the CFG batch [uncond | cond] (one object per half when dual_stream)."""
-        if self.dual_stream:
-            return (self.unet.precompute_context(uncond.contiguous()), self.unet.precompute_context(cond.contiguous()))
-        return self.unet.precompute_context(torch.cat([uncond, cond]).contiguous())
+        """Step-invariant text-context K/V of the CFG batch [uncond | cond] (one object per half when dual_stream).
+        The objects are owned by the sampler and refilled IN PLACE for every prompt of the same batch size: the captured
+        UNet step reads their buffers, so they must not move between images."""
+        key = (tuple(uncond.shape), str(uncond.device), self.dual_stream)
+        halves = (uncond.contiguous(), cond.contiguous()) if self.dual_stream else (torch.cat([uncond, cond]).contiguous(),)
+        if getattr(self, "_cc_key", None) != key:
+            self._cc = tuple(self.unet.precompute_context(h) for h in halves)
+            self._cc_key = key
+        else:
+            for c, h in zip(self._cc, halves):
+                c.update(h)
+        return self._cc if self.dual_stream else self._cc[0]
+
+    def _static_xc(self, shape, dev):
+        """The UNet input buffer [x | mask | masked latent] x [uncond, cond]: static, the captured step reads it."""
+        xc = getattr(self, "_xc", None)
+        if xc is None or tuple(xc.shape) != tuple(shape) or xc.device != dev:
+            self._xc = xc = torch.empty(shape, dtype=torch.float32, device=dev)
+        return xc
 
     @staticmethod
     def _half(t_buf, b, which):
@@ -102,6 +117,8 @@ class Sampler(object):
     def _unet_step(self, xc, t_buf, cc, use_graph):
         if not use_graph:
             return self._unet_eval(xc, t_buf, cc)
+        # the graph is valid while the buffers it read are alive and in place: key on the objects that own them (the
+        # sampler keeps xc, the TimeEmb row and the ContextKV alive; a caller's own buffers must outlive the graph)
         key = (xc.data_ptr(), t_buf.table.data_ptr() if hasattr(t_buf, "table") else t_buf.data_ptr(), id(cc), tuple(xc.shape))
         if self._gkey != key:
             self._unet_eval(xc, t_buf, cc)                      # warm-up: weight pre-pack, allocator pools
@@ -109,7 +126,7 @@ class Sampler(object):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self._unet_eval(xc, t_buf, cc)
-            self._graph, self._gout, self._gkey = g, out, key
+            self._graph, self._gout, self._gkey, self._gkeep = g, out, key, (xc, t_buf, cc)
         self._graph.replay()
         return self._gout
 
@@ -122,7 +139,7 @@ class Sampler(object):
         total = ts.shape[0]
         b, _, h, w = x_T.shape
         dev = x_T.device
-        xc = torch.empty((2 * b, 4 + c_concat.shape[1], h, w), dtype=torch.float32, device=dev)
+        xc = self._static_xc((2 * b, 4 + c_concat.shape[1], h, w), dev)
         xc[:b, :4] = x_T
         xc[b:, :4] = x_T
         xc[:b, 4:] = c_concat

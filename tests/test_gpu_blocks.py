@@ -112,6 +112,22 @@ def test_ddim_trajectory_golden(golden, nets):
     assert psnr >= (40.0 if _tol() == 1.0 else 30.0)
 
 
+def test_graph_sampler_across_prompts_equals_eager(nets):
+    """The captured UNet step is reused across images: a second image with another prompt, mask and noise must equal
+    the eager (no graph) run bit for bit (the step reads the sampler's static buffers, refilled in place per image)."""
+    from stable_diffusion_amd.sampler import Sampler
+    unet, vae = nets[0], nets[1]
+    dev = lambda t: t.to(DEV)
+    s_graph, s_eager = Sampler(unet, vae), Sampler(unet, vae)
+    for seed in (100, 7, 8):
+        inp = make_inputs(1, 32, 4, seed=seed)
+        args = (4, dev(inp["cond"]), dev(inp["uncond"]), dev(inp["c_concat"]), dev(inp["x_T"]), [dev(n) for n in inp["noises"]], 9.0)
+        xg, ig = s_graph.sample(*args, use_graph=True)
+        xe, ie = s_eager.sample(*args, use_graph=False)
+        assert torch.equal(xg, xe) and torch.equal(ig, ie), seed
+    assert s_graph._graph is not None
+
+
 def test_unet_256px_vs_oracle_and_batch_invariance(nets):
     """L=32 (256x256) CFG batch: HIP vs the CPU oracle; and a batch of 2 images equals the two images run alone,
     bit for bit (images never interact; the multi-GPU sharding relies on it)."""
