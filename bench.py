@@ -203,10 +203,16 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel: every C-ABI launch of one eager UNet step + one decode bracketed by HIP events on its stream
+        # eager launches cost the host ~25 us each, more than many kernels run: give the GPU a head start of spinning so
+        # that the launches queue up and each event pair brackets the kernel alone, not the wait for its launch
         with _lib.KernelTimer(work_of) as kt:
+            torch.cuda._sleep(int(60e6))
             unet(xc, timesteps=tb, context=cc)
             n_unet = len(kt.records)
-            vae.decode(x_T / 0.18215)
+            zdec = x_T / 0.18215
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(60e6))
+            vae.decode(zdec)
         summ = kt.summary()
         # weight each entry point by its share of an image: 50 UNet steps + 1 decode
         tot = {}

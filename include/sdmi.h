@@ -118,6 +118,11 @@ void sdmi_tune_override(int tile, int splits);
  * fewer bytes staged), -1 = automatic (default: shared window wherever it applies, env SDMI_CONV_WIN=0 turns it off). */
 void sdmi_tune_conv_window(int on);
 
+/* Profiling aid, no counterpart in the reference: `event` (a hipEvent_t, or NULL to clear) is recorded by the NEXT
+ * sdmi_gemm / sdmi_conv3x3 call that splits K, on that call's stream, between its main kernel and its fixed-order
+ * reduce kernel; one-shot.  bench.py's roofline pass uses it to time the two kernels apart. */
+void sdmi_prof_mid_event(void* event);
+
 /* ---- skinny linear for M <= 64 rows: Unet.time_embed (Unet.py:41-45) and every ResBlock.emb_proj
  *      (layers/ResBlock.py:70) batched into one launch. x fp32 [M][K]; w bf16 [N][K]; out fp32 [M][N];
  *      SDMI_F_SILU applies SiLU to x on load. */

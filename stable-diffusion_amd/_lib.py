@@ -37,6 +37,7 @@ PROTOTYPES = {
     "sdmi_gemm_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _u32]),
     "sdmi_tune_override": (None, [_i, _i]),
     "sdmi_tune_conv_window": (None, [_i]),
+    "sdmi_prof_mid_event": (None, [_vp]),
     "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
     "sdmi_timestep_embedding": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),
@@ -106,16 +107,27 @@ def call(name, *args):
         import torch
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        mid = None
+        if name in ("sdmi_conv3x3", "sdmi_gemm"):
+            # a split-K launch records this event between its main kernel and its fixed-order reduce kernel
+            mid = torch.cuda.Event(enable_timing=True)
+            mid.record(st)                      # creates the handle; the library records it again if it splits K
+            lib.sdmi_prof_mid_event(C.c_void_p(mid.cuda_event))
         e0.record(st)
         rc = getattr(lib, name)(*args)
         e1.record(st)
-        if name in ("sdmi_conv3x3", "sdmi_gemm"):
-            # kernel symbol as rocprofv3 reports it; a split-K launch is keyed on its main kernel (its fixed-order
-            # reduce kernel, a few us, rides inside the same event pair)
-            name = (lib.sdmi_last_kernel().decode() or name).split(" + ")[0]
+        if mid is not None:
+            lib.sdmi_prof_mid_event(None)
+            kern = (lib.sdmi_last_kernel().decode() or name).split(" + ")   # kernel symbols as rocprofv3 reports them
+            name = kern[0]
+            if len(kern) > 1:
+                TIMER.records.append((name, TIMER.work_fn(name, args), e0, mid))
+                TIMER.records.append((kern[1], (0.0, 0.0), mid, e1))
+                e0 = None
         elif name == "sdmi_attention":
             name = "attn64_kernel"
-        TIMER.records.append((name, TIMER.work_fn(name, args), e0, e1))
+        if e0 is not None:
+            TIMER.records.append((name, TIMER.work_fn(name, args), e0, e1))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

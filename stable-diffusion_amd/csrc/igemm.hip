@@ -788,6 +788,15 @@ static int g_force_tile = -1, g_force_splits = -1, g_force_window = -1;
 extern "C" void sdmi_tune_override(int tile, int splits) { g_force_tile = tile; g_force_splits = splits; }
 extern "C" void sdmi_tune_conv_window(int on) { g_force_window = on; }
 
+// Profiling aid (bench.py's roofline pass): an event the next split-K launch records on its stream BETWEEN the main
+// kernel and the fixed-order reduce kernel, so that a caller bracketing the entry point with two events of its own can
+// price the two kernels apart.  One-shot: cleared by the launch that uses it (and by passing NULL).
+static hipEvent_t g_mid_event = nullptr;
+extern "C" void sdmi_prof_mid_event(void* ev) { g_mid_event = (hipEvent_t)ev; }
+static void record_mid_event(hipStream_t st) {
+  if (g_mid_event) { (void)hipEventRecord(g_mid_event, st); g_mid_event = nullptr; }
+}
+
 static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags, bool conv) {
   if (flags & SDMI_F_GEGLU) return 1;
   if (g_force_splits > 0) return g_force_splits > nk ? nk : g_force_splits;
@@ -964,6 +973,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
       long long items = (long long)batch * p.M * (p.npad / 4);
       long long rb = (items + 255) / 256;
       if (rb > 4096) rb = 4096;
+      record_mid_event(st);
       hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
       return sdmi_check_launch("split-K reduce");
     }
@@ -982,6 +992,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   long long items = (long long)batch * p.M * (p.npad / 4);
   long long rb = (items + 255) / 256;
   if (rb > 4096) rb = 4096;
+  record_mid_event(st);
   hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
   return sdmi_check_launch("split-K reduce");
 }
