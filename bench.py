@@ -11,6 +11,7 @@ outputs per step (weak scaling).  Prints ONE JSON line on rank 0 with `roofline`
 `cpu_baseline` (the fp32 oracle timed on the host cores, rank 0, N=1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -187,6 +188,29 @@ def main():
     torch.cuda.synchronize()
     dec_ms = e0.elapsed_time(e1)
 
+    def measured_peaks():
+        """MFMA issue rate (v_mfma_f32_32x32x16 only, two waves per SIMD) and streaming-copy bandwidth of THIS box."""
+        st = torch.cuda.current_stream()
+        sp = ctypes.c_void_p(st.cuda_stream)
+        scratch = torch.zeros(16, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        blocks, iters = 256 * 2, 20000
+        _lib.call("sdmi_probe_mfma", scratch.data_ptr(), blocks, 200, sp)
+        e0.record(st); _lib.call("sdmi_probe_mfma", scratch.data_ptr(), blocks, iters, sp); e1.record(st)
+        torch.cuda.synchronize()
+        mfma = blocks * 4 * iters * 8 * (2.0 * 32 * 32 * 16) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        n = 1 << 30
+        src, dst = torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+        src.zero_()
+        _lib.call("sdmi_probe_copy", src.data_ptr(), dst.data_ptr(), n, sp)
+        e0.record(st)
+        for _ in range(5):
+            _lib.call("sdmi_probe_copy", src.data_ptr(), dst.data_ptr(), n, sp)
+        e1.record(st)
+        torch.cuda.synchronize()
+        hbm = 5 * 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        return {"mfma_tflops": mfma, "hbm_copy_gbs": hbm}
+
     roof, kernels = None, None
     traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
     pmc_traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
@@ -232,6 +256,11 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": ach / PEAK_HBM_GBS, "traffic": traffic_of(dom), "avg_launch_ms": d["ms"] / d["launches"],
                     "launches_per_image": d["launches"], "share_of_image_time": d["ms"] / sum(v["ms"] for v in tot.values())}
+        # the same fraction against what this box measures: `peak` / `frac` above stay the nominal ones
+        mp = measured_peaks()
+        roof["peak_measured"] = mp["mfma_tflops"] if roof["bound"] == "mfma" else mp["hbm_copy_gbs"]
+        roof["frac_of_measured"] = roof["achieved"] / roof["peak_measured"]
+        roof["measured_peaks"] = mp
         kernels = {k: {"ms_per_image": round(v["ms"], 3), "launches": v["launches"],
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                        "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}

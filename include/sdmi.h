@@ -154,6 +154,13 @@ int sdmi_cfg_ddim_step(const float* eps, const float* x, const float* noise, flo
                        float a_prev, float sigma, float temperature, float* x_out, float* pred_x0, float* xc_out,
                        int xc_channels, int b, int chw, void* stream);
 
+/* ---- measurement probes, no counterpart in the reference (roofline fractions are reported against the
+ *      nominal and the MEASURED peak of the box).  sdmi_probe_mfma launches `blocks` blocks of 4 waves that each issue
+ *      8 * iters v_mfma_f32_32x32x16 (2*32*32*16 flop each) and nothing else; sdmi_probe_copy streams `bytes` from src
+ *      to dst with 16-byte accesses.  The caller times them (HIP events).  scratch: >= 4 bytes of device memory. */
+int sdmi_probe_mfma(float* scratch, int blocks, int iters, void* stream);
+int sdmi_probe_copy(const void* src, void* dst, int64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

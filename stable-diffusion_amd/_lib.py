@@ -38,6 +38,8 @@ PROTOTYPES = {
     "sdmi_tune_override": (None, [_i, _i]),
     "sdmi_tune_conv_window": (None, [_i]),
     "sdmi_prof_mid_event": (None, [_vp]),
+    "sdmi_probe_mfma": (_i, [_vp, _i, _i, _vp]),
+    "sdmi_probe_copy": (_i, [_vp, _vp, _i64, _vp]),
     "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
     "sdmi_timestep_embedding": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),

@@ -282,3 +282,28 @@ def test_splitk_conv_and_gemm_batch_invariant():
     A = E.Act(a.to(H16).to(DEV).reshape(2, 144, k), 2, 12, 12, k)
     o = E.gemm(A, w2.to(H16).to(DEV).contiguous(), nn)
     _check(o.buf.reshape(m, nn), a @ w2.t(), 1.5e-3, 6e-4, "split-K gemm")
+
+
+def test_measurement_probes():
+    """bench.py's measured-peak probes run and give figures of the right order (MI355X: ~2 PFLOP/s, ~4-5 TB/s copy)."""
+    import ctypes
+    from stable_diffusion_amd import _lib
+    st = torch.cuda.current_stream()
+    sp = ctypes.c_void_p(st.cuda_stream)
+    scratch = torch.zeros(16, device=DEV)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _lib.call("sdmi_probe_mfma", scratch.data_ptr(), 512, 100, sp)
+    e0.record(st); _lib.call("sdmi_probe_mfma", scratch.data_ptr(), 512, 5000, sp); e1.record(st)
+    torch.cuda.synchronize()
+    tf = 512 * 4 * 5000 * 8 * (2.0 * 32 * 32 * 16) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    n = 1 << 28
+    src = torch.arange(n // 8, dtype=torch.int64, device=DEV)
+    dst = torch.zeros_like(src)
+    _lib.call("sdmi_probe_copy", src.data_ptr(), dst.data_ptr(), n, sp)
+    e0.record(st); _lib.call("sdmi_probe_copy", src.data_ptr(), dst.data_ptr(), n, sp); e1.record(st)
+    torch.cuda.synchronize()
+    gbs = 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    print("probe: %.0f TFLOP/s MFMA issue, %.0f GB/s copy" % (tf, gbs))
+    assert torch.equal(src, dst)
+    assert scratch.abs().max().item() == 0.0
+    assert 500.0 < tf < 6000.0 and 500.0 < gbs < 20000.0
