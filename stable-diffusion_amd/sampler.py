@@ -45,7 +45,9 @@ class Sampler(object):
         self._gkey = None
         # dual_stream: evaluate the unconditional and the conditional half of the CFG batch as two independent UNet
         # passes on two HIP streams (per-image results do not depend on the batch, so the bits are the same)
-        self.dual_stream = (os.environ.get("SDMI_DUAL_STREAM", "0") == "1") if dual_stream is None else bool(dual_stream)
+        # Default on: +2.8 % images/s at 768x768 b=1 (the latency-bound 24x24 / 12x12 levels of one half fill the gaps
+        # of the other); SDMI_DUAL_STREAM=0 runs the CFG batch as one pass.
+        self.dual_stream = (os.environ.get("SDMI_DUAL_STREAM", "1") == "1") if dual_stream is None else bool(dual_stream)
         self._side = None
 
     def _time_tables(self, steps, bc, dev):
