@@ -12,4 +12,6 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out
 echo write done
 find gpurun_out/final -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
 # the raw traces are large: keep the summaries
+python3 profiles/trace_window.py $(find gpurun_out/final/kt -name "*kernel_trace.csv" | head -1) > gpurun_out/final/roofline_pass_kernel_stats.csv || exit 5
+head -5 gpurun_out/final/roofline_pass_kernel_stats.csv
 find gpurun_out/final -name "*kernel_trace.csv" -delete
