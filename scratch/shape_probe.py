@@ -8,8 +8,9 @@ dev = torch.device("cuda", 0)
 _lib.load(); torch.set_grad_enabled(False)
 unet, vae = bench.build_models(dev)
 unet = unet.to(dev)
-x = torch.randn(2, 9, 96, 96, device=dev); t = torch.full((2,), 501, dtype=torch.long, device=dev)
-ctx = unet.precompute_context(torch.randn(2, 77, 1024, device=dev)); te = unet.precompute_time_embedding(t)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+x = torch.randn(B, 9, 96, 96, device=dev); t = torch.full((B,), 501, dtype=torch.long, device=dev)
+ctx = unet.precompute_context(torch.randn(B, 77, 1024, device=dev)); te = unet.precompute_time_embedding(t)
 for _ in range(2): unet(x, timesteps=te, context=ctx)
 torch.cuda.synchronize()
 with _lib.KernelTimer(bench.work_of) as kt:
