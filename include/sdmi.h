@@ -34,6 +34,9 @@ extern "C" {
 #define SDMI_F_UPSAMPLE2X 32u   /* conv: input is read through a nearest 2x upsample gather  */
 #define SDMI_F_SILU 64u     /* groupnorm_apply / small linear: SiLU                           */
 #define SDMI_F_OUT_F32 128u /* gemm: store fp32 row-major (ldc in elements) instead of bf16  */
+#define SDMI_F_OUT_U8_IMAGE 256u /* conv3x3: store uint8 NHWC (n, hout, wout, cout), tightly packed, of
+                                   * clamp((y + 1) / 2, 0, 1) * 255 truncated: the image post-processing at
+                                   * LatentDiffusionInpainting.py:228-230 fused into the decoder's conv_out */
 
 int sdmi_version(void);
 /* 16-bit storage type ("h16") of activations and packed weights this build uses: 0 = IEEE fp16 (default), 1 = bf16 */

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDMI_LIB_PATH") or os.path.join(_HERE, "libsdmi355.so")   # env: A/B another build of the library
 
 # flags (sdmi.h)
-F_BIAS, F_ROWBIAS, F_RESIDUAL, F_GEGLU, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_SILU, F_OUT_F32 = 1, 2, 4, 8, 16, 32, 64, 128
+F_BIAS, F_ROWBIAS, F_RESIDUAL, F_GEGLU, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_SILU, F_OUT_F32, F_OUT_U8_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 

@@ -74,7 +74,17 @@ __device__ __forceinline__ void epilogue4(const IgemmParams& p, int bz, int m, i
       for (int e = 0; e < 4; ++e) if (n0 + e < p.N) y[e] += h2f(r[e]);
     }
   }
-  if (fl & SDMI_F_OUT_NCHW_F32) {
+  if (fl & SDMI_F_OUT_U8_IMAGE) {
+    // torch.clamp((out + 1.0) / 2.0, 0, 1) * 255 -> uint8 (truncation), the reference's fp32 operation order
+    unsigned char* o = (unsigned char*)p.out + (long long)m * p.N + n0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (full || n0 + e < p.N) {
+        float v = (y[e] + 1.0f) / 2.0f;
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        o[e] = (unsigned char)(v * 255.0f);
+      }
+  } else if (fl & SDMI_F_OUT_NCHW_F32) {
     float* o = (float*)p.out + ((long long)sample * p.N + n0) * hwo + pix;
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (full || n0 + e < p.N) o[(long long)e * hwo] = y[e];
@@ -919,7 +929,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   {
     const uint32_t fl = p.flags;
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    bool fast = !(fl & SDMI_F_OUT_NCHW_F32) && p.N % 8 == 0 && p.ldc % 8 == 0 && al16(p.out) && p.sc % 8 == 0;
+    bool fast = !(fl & (SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE)) && p.N % 8 == 0 && p.ldc % 8 == 0 && al16(p.out) && p.sc % 8 == 0;
     if (fl & SDMI_F_GEGLU) fast = fast && bn / tv.wn >= 64 && p.N % 32 == 0;
     if (fl & SDMI_F_BIAS) fast = fast && al16(p.bias);
     if (fl & SDMI_F_ROWBIAS) fast = fast && al16(p.rowbias) && p.ldrb % 4 == 0 && p.rows_per_sample >= bm;
@@ -1012,6 +1022,7 @@ extern "C" int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int 
   SDMI_REQUIRE(k % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k, "gemm: k/lda/ldw must be multiples of 8 (k=%d lda=%d ldw=%d)", k, lda, ldw);
   SDMI_REQUIRE(aligned16(a) && aligned16(w) && aligned16(out), "gemm: pointers must be 16-byte aligned");
   SDMI_REQUIRE(sa % 8 == 0 && sw % 8 == 0 && sc % 4 == 0, "gemm: batch strides must keep 16-byte alignment");
+  SDMI_REQUIRE(!(flags & SDMI_F_OUT_U8_IMAGE), "gemm: SDMI_F_OUT_U8_IMAGE is a conv3x3 output mode");
   SDMI_REQUIRE(!(flags & SDMI_F_BIAS) || bias, "gemm: SDMI_F_BIAS without bias");
   SDMI_REQUIRE(!(flags & SDMI_F_ROWBIAS) || (rowbias && rows_per_sample > 0), "gemm: SDMI_F_ROWBIAS without rowbias/rows_per_sample");
   SDMI_REQUIRE(!(flags & SDMI_F_RESIDUAL) || (residual && ldr % 4 == 0 && ((uintptr_t)residual & 7) == 0), "gemm: bad residual");
@@ -1048,7 +1059,8 @@ extern "C" int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin
   SDMI_REQUIRE(!(flags & SDMI_F_ROWBIAS) || rowbias, "conv3x3: SDMI_F_ROWBIAS without rowbias");
   SDMI_REQUIRE(!(flags & SDMI_F_RESIDUAL) || (residual && ldr % 4 == 0 && ((uintptr_t)residual & 7) == 0), "conv3x3: bad residual");
   SDMI_REQUIRE(!(flags & (SDMI_F_GEGLU | SDMI_F_OUT_F32)), "conv3x3: unsupported flag");
-  if (!(flags & SDMI_F_OUT_NCHW_F32)) SDMI_REQUIRE(ldc % 4 == 0 && ldc >= cout, "conv3x3: ldc");
+  SDMI_REQUIRE(!(flags & SDMI_F_OUT_U8_IMAGE) || !(flags & SDMI_F_OUT_NCHW_F32), "conv3x3: two output layouts requested");
+  if (!(flags & (SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE))) SDMI_REQUIRE(ldc % 4 == 0 && ldc >= cout, "conv3x3: ldc");
   IgemmParams p = {};
   p.a = (const u16*)x; p.w = (const u16*)w_packed; p.out = out; p.bias = bias; p.rowbias = rowbias; p.res = (const u16*)residual;
   p.lda = ldx; p.ldw = 9 * cin; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;

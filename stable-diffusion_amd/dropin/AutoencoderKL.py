@@ -120,7 +120,7 @@ class Decoder(nn.Module):
         self.norm_out = nn.GroupNorm(num_groups=32, num_channels=block_in, eps=1e-6, affine=True)
         self.conv_out = nn.Conv2d(block_in, 3, kernel_size=3, stride=1, padding=1)
 
-    def run(self, z, taps=None):
+    def run(self, z, taps=None, image_u8=False):
         h = _conv_in(z, self.conv_in)
         h = self.mid.block_2.run(self.mid.attn_1.run(self.mid.block_1.run(h)))
         if taps is not None:
@@ -133,6 +133,8 @@ class Decoder(nn.Module):
             if taps is not None:
                 taps["up.%d" % lvl] = h
         h = E.groupnorm(h, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps, silu=True)
+        if image_u8:  # (n, H, W, 3) uint8 straight from conv_out's epilogue (LatentDiffusionInpainting.py:228-230)
+            return E.conv3x3(h, self.conv_out.weight, self.conv_out.bias, out_u8_image=True)
         return E.conv3x3(h, self.conv_out.weight, self.conv_out.bias, out_nchw=True)
 
     @torch.no_grad()
@@ -181,3 +183,10 @@ class AutoencoderKL(nn.Module):
     @torch.no_grad()
     def decode(self, z):
         return self.decoder(_conv1x1_nchw(z.contiguous().float(), self.post_quant_conv))
+
+    @torch.no_grad()
+    def decode_image_u8(self, z):
+        """decode(z) followed by the reference's image post-processing `clamp((x + 1) / 2, 0, 1) * 255 -> uint8`,
+        (n, H, W, 3) as PIL takes it, with the post-processing done in the last conv's epilogue (same bits as
+        `(torch.clamp((decode(z) + 1.0) / 2.0, 0.0, 1.0).permute(0, 2, 3, 1) * 255).to(torch.uint8)`)."""
+        return self.decoder.run(_conv1x1_nchw(z.contiguous().float(), self.post_quant_conv), image_u8=True)

@@ -195,7 +195,7 @@ def layernorm(a, weight, bias, eps=1e-5):
 
 
 def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias=None, ldrb=0, residual=None,
-            out=None, out_nchw=False):
+            out=None, out_nchw=False, out_u8_image=False):
     """3x3 conv. pad = (left, right, top, bottom) as F.pad takes it. rowbias: fp32 tensor/ptr (per-sample channel add)."""
     wp = packed_conv3x3(weight)
     cout, cin = weight.shape[0], weight.shape[1]
@@ -218,7 +218,12 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
     if residual is not None:
         flags |= L.F_RESIDUAL
         res_ptr, ldr = residual.ptr, residual.ld
-    if out_nchw:
+    if out_u8_image:
+        # uint8 (n, ho, wo, cout) image: clamp((y + 1) / 2, 0, 1) * 255 in the conv epilogue
+        flags |= L.F_OUT_U8_IMAGE
+        res = torch.empty((a.n, ho, wo, cout), dtype=torch.uint8, device=a.device)
+        optr, ldc = res.data_ptr(), 0
+    elif out_nchw:
         flags |= L.F_OUT_NCHW_F32
         res = torch.empty((a.n, cout, ho, wo), dtype=torch.float32, device=a.device)
         optr, ldc = res.data_ptr(), 0

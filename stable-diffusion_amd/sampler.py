@@ -167,6 +167,4 @@ class Sampler(object):
 
     @torch.no_grad()
     def decode_to_uint8(self, latent):
-        out = self.vae.decode(1. / SCALE_FACTOR * latent)
-        img = torch.clamp((out + 1.0) / 2.0, min=0.0, max=1.0)
-        return (img.permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous()
+        return self.vae.decode_image_u8(1. / SCALE_FACTOR * latent)

@@ -149,3 +149,16 @@ def test_vae_decode_256px_vs_oracle(nets):
     _, vae, _, sd_v = nets
     z = T(np.random.RandomState(6).randn(1, 4, 32, 32).astype(np.float32))
     _check(vae.decode(z.to(DEV)), O.vae_decode(sd_v, z).numpy(), 7e-3, 5e-3, "decode L=32 vs oracle")
+
+
+def test_decode_image_u8_equals_reference_postprocessing(nets):
+    """uint8 HWC image from conv_out's epilogue == the reference's clamp((x+1)/2)*255 -> uint8 applied to decode(z)
+    (LatentDiffusionInpainting.py:228-230), bit for bit; values straddling 0 and 255 are in range of the test."""
+    vae = nets[1]
+    z = T(np.random.RandomState(21).randn(2, 4, 24, 16).astype(np.float32) * 3.0).to(DEV)
+    out = vae.decode(z)
+    ref = (torch.clamp((out + 1.0) / 2.0, min=0.0, max=1.0).permute(0, 2, 3, 1) * 255).to(torch.uint8)
+    img = vae.decode_image_u8(z)
+    assert img.dtype == torch.uint8 and img.shape == (2, 192, 128, 3)
+    assert torch.equal(img, ref)
+    assert (ref == 0).any() and (ref == 255).any() and ((ref > 0) & (ref < 255)).any()
