@@ -162,3 +162,22 @@ def test_decode_image_u8_equals_reference_postprocessing(nets):
     assert img.dtype == torch.uint8 and img.shape == (2, 192, 128, 3)
     assert torch.equal(img, ref)
     assert (ref == 0).any() and (ref == 255).any() and ((ref > 0) & (ref < 255)).any()
+
+
+def test_prepare_c_concat_matches_oracle(nets):
+    """On-device image conditioning (mask resize, masked image, 0.18215 * VAE-encode sample) against the CPU oracle's
+    encoder with the same posterior noise (reference LatentDiffusionInpainting.py:77-79, :279-293)."""
+    from stable_diffusion_amd.sampler import Sampler
+    unet, vae, _, sd_v = nets
+    rs = np.random.RandomState(31)
+    image = T(np.tanh(rs.randn(1, 3, 64, 96)).astype(np.float32))
+    mask = torch.zeros(1, 1, 64, 96)
+    mask[:, :, 10:40, 20:70] = 1.0
+    noise = T(rs.randn(1, 4, 8, 12).astype(np.float32))
+    cc = Sampler(unet, vae).prepare_c_concat(image.to(DEV), mask.to(DEV), noise.to(DEV)).cpu()
+    assert cc.shape == (1, 5, 8, 12)
+    assert torch.equal(cc[:, :1], torch.nn.functional.interpolate(mask, size=(8, 12)))        # nearest, as the reference
+    mom = O.vae_encode_moments(sd_v, image * (mask < 0.5))
+    mean, logvar = torch.chunk(mom, 2, dim=1)
+    ref = 0.18215 * (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise)
+    _check(cc[:, 1:], ref.numpy(), 5e-3, 3e-3, "masked-image latents")   # measured 1.5e-3 / 8.4e-4
