@@ -290,6 +290,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()   # rank 0 runs the roofline pass after the timed region: keep the group alive until it is done
         dist.destroy_process_group()
 
 
