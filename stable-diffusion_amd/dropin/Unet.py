@@ -135,11 +135,37 @@ class Unet(nn.Module):
     def forward(self, x, timesteps=None, context=None):
         if isinstance(context, list):
             context = context[0]
+        st = self._begin(x, timesteps)
+        return self._finish(st, context)
+
+    @torch.no_grad()
+    def cfg_prefix(self, x, timesteps):
+        """The part of forward() that does not see the text context: conv_in, the first ResBlock and the first
+        SpatialTransformer up to and including its self-attention.  The two halves of a classifier-free-guidance batch
+        share latent, timestep and image conditioning (LatentDiffusionInpainting.py:179-193) and differ only in the
+        prompt, so a sampler computes this once and continues it twice: `forward_from_prefix(p, ctx_uncond)` and
+        `forward_from_prefix(p.branch(), ctx_cond)`.  Same kernels on the same shapes: the bits of forward()."""
+        st = self._begin(x, timesteps)
+        first = self.input_blocks[1]
+        assert isinstance(first[0], ResBlock) and isinstance(first[1], SpatialTransformer), "unexpected first stage"
+        st.a1 = first[0].run(st.h, st.emb[id(first[0])], st.ldrb)
+        st.t1 = first[1].run_prefix(st.a1)
+        return st
+
+    @torch.no_grad()
+    def forward_from_prefix(self, st, context):
+        if isinstance(context, list):
+            context = context[0]
+        return self._finish(st, context)
+
+    def _begin(self, x, timesteps):
+        """Geometry, the concat buffers of the skip connections, the timestep-embedding table and conv_in."""
         x = x.contiguous().float()
         n, _, hh, ww = x.shape
         dev = x.device
-        keep, emb, ldrb = self._emb_pointers(timesteps.table if isinstance(timesteps, TimeEmb) else self._embeddings(timesteps))
-        ctx = context if isinstance(context, ContextKV) else self.precompute_context(context)
+        st = _FwdState()
+        st.keep, st.emb, st.ldrb = self._emb_pointers(timesteps.table if isinstance(timesteps, TimeEmb) else self._embeddings(timesteps))
+        st.n, st.dev = n, dev
 
         # ---- geometry + concat plan: skip k is consumed by output block (K-1-k) next to an `h` of cat_c1[k] channels
         nin = len(self.input_blocks)
@@ -155,24 +181,42 @@ class Unet(nn.Module):
                 c = blk[0].conv1.out_channels
             skip_c.append(c)
             skip_hw.append((ch_h, ch_w))
+        st.skip_c, st.skip_hw = skip_c, skip_hw
+        st.cat = self._new_cat(st)
+        blk = self.input_blocks[0]
+        assert isinstance(blk, nn.Conv2d)
+        dst = st.cat[0].cols(st.cat[0].c - skip_c[0], skip_c[0])
+        E.L.call("sdmi_conv3x3_in", x.data_ptr(), n, x.shape[1], hh, ww, blk.weight.data_ptr(), blk.bias.data_ptr(),
+                 blk.out_channels, dst.ptr, dst.ld, E._stream())
+        st.h = dst
+        st.a1 = st.t1 = None
+        return st
+
+    def _new_cat(self, st):
+        nin = len(self.input_blocks)
         cat = [None] * nin
         for j, blk in enumerate(self.output_blocks):
             k = nin - 1 - j
-            c1 = blk[0].norm1.num_channels - skip_c[k]
-            sh, sw = skip_hw[k]
-            cat[k] = E.new_act(n, sh, sw, c1 + skip_c[k], dev)
-        c1_of = lambda k: cat[k].c - skip_c[k]
+            c1 = blk[0].norm1.num_channels - st.skip_c[k]
+            sh, sw = st.skip_hw[k]
+            cat[k] = E.new_act(st.n, sh, sw, c1 + st.skip_c[k], st.dev)
+        return cat
 
+    def _finish(self, st, context):
+        ctx = context if isinstance(context, ContextKV) else self.precompute_context(context)
+        emb, ldrb, cat, skip_c = st.emb, st.ldrb, st.cat, st.skip_c
+        nin = len(self.input_blocks)
+        c1_of = lambda k: cat[k].c - skip_c[k]
         # ---- down path: block i writes its output into the upper half of cat[i]
-        h = None
+        h = st.h
         for i, blk in enumerate(self.input_blocks):
+            if i == 0:
+                continue                                   # conv_in: done by _begin
             dst = cat[i].cols(c1_of(i), skip_c[i])
-            if isinstance(blk, nn.Conv2d):
-                E.L.call("sdmi_conv3x3_in", x.data_ptr(), n, x.shape[1], hh, ww, blk.weight.data_ptr(), blk.bias.data_ptr(),
-                         blk.out_channels, dst.ptr, dst.ld, E._stream())
-                h = dst
-            elif isinstance(blk, Downsample):
+            if isinstance(blk, Downsample):
                 h = blk.run(h, out=dst)
+            elif i == 1 and st.t1 is not None:             # continue the shared context-free prefix
+                h = blk[1].run(st.a1, ctx, out=dst, prefix=st.t1)
             else:
                 h = self._run_stage(blk, h, emb, ldrb, ctx, dst)
         # ---- middle: result goes into the lower half of the deepest concat buffer
@@ -187,5 +231,19 @@ class Unet(nn.Module):
             h = self._run_stage(blk, cat[k], emb, ldrb, ctx, dst)
         gn, conv = self.out[0], self.out[2]
         h = E.groupnorm(h, gn.weight, gn.bias, gn.eps, silu=True)
-        del keep
         return E.conv3x3(h, conv.weight, conv.bias, out_nchw=True)
+
+
+class _FwdState(object):
+    """What forward() has built before the text context is needed (see Unet.cfg_prefix)."""
+
+    def branch(self, unet):
+        """A second continuation of the same prefix: its own concat buffers (the up path writes into them) holding a copy
+        of the one skip tensor computed so far; the first ResBlock's output and the token stream are only read."""
+        o = _FwdState()
+        o.__dict__.update(self.__dict__)
+        o.cat = unet._new_cat(self)
+        c0, k0 = self.cat[0], self.skip_c[0]
+        o.cat[0].buf[..., o.cat[0].c - k0:o.cat[0].c].copy_(c0.buf[..., c0.c - k0:c0.c])
+        o.h = o.cat[0].cols(o.cat[0].c - k0, k0)
+        return o

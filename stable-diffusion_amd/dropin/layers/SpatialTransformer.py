@@ -157,8 +157,13 @@ class BasicTransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.norm3 = nn.LayerNorm(dim)
 
-    def run(self, t, context=None, taps=None):
-        t = self.attn1.run(E.layernorm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps), None, residual=t)
+    def run_attn1(self, t):
+        """The context-free head of the block: x + attn1(LN(x))."""
+        return self.attn1.run(E.layernorm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps), None, residual=t)
+
+    def run(self, t, context=None, taps=None, after_attn1=False):
+        if not after_attn1:
+            t = self.run_attn1(t)
         if taps is not None:
             taps["attn1"] = t
         t = self.attn2.run(E.layernorm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps), context, residual=t)
@@ -183,10 +188,21 @@ class SpatialTransformer(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, context_dim=1024)])
         self.proj_out = zero_module(nn.Linear(in_channels, inner))
 
-    def run(self, a, context=None, out=None, taps=None):
+    def run_prefix(self, a):
+        """Everything before the text context enters (GroupNorm, proj_in, LayerNorm, self-attention + residual): the token
+        stream that `run(a, context, prefix=...)` continues from.  Depends on `a` only, so the two halves of a CFG batch
+        (same latent, same timestep, different prompt) can share it."""
         xn = E.groupnorm(a, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
         t = E.gemm(xn, E.packed_linear((self.proj_in.weight,)), self.proj_in.weight.shape[0], bias=self.proj_in.bias)
-        t = self.transformer_blocks[0].run(t, context, taps)
+        return self.transformer_blocks[0].run_attn1(t)
+
+    def run(self, a, context=None, out=None, taps=None, prefix=None):
+        if prefix is None:
+            xn = E.groupnorm(a, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
+            t = E.gemm(xn, E.packed_linear((self.proj_in.weight,)), self.proj_in.weight.shape[0], bias=self.proj_in.bias)
+            t = self.transformer_blocks[0].run(t, context, taps)
+        else:
+            t = self.transformer_blocks[0].run(prefix, context, taps, after_attn1=True)
         return E.gemm(t, E.packed_linear((self.proj_out.weight,)), self.proj_out.weight.shape[0], bias=self.proj_out.bias,
                       residual=a, out=out)
 

@@ -49,6 +49,9 @@ class Sampler(object):
         # of the other); SDMI_DUAL_STREAM=0 runs the CFG batch as one pass.
         self.dual_stream = (os.environ.get("SDMI_DUAL_STREAM", "1") == "1") if dual_stream is None else bool(dual_stream)
         self._side = None
+        # the context-free head of the UNet is the same for the unconditional and the conditional half (sample() feeds
+        # both the same latent / timestep / image conditioning): compute it once per step.  SDMI_SHARE_PREFIX=0: A/B.
+        self.share_prefix = os.environ.get("SDMI_SHARE_PREFIX", "1") == "1"
 
     def _time_tables(self, steps, bc, dev):
         w = self.unet.time_embed[0].weight
@@ -108,6 +111,19 @@ class Sampler(object):
             torch.cuda.synchronize()
             self._side = torch.cuda.Stream()
         side = self._side
+        if self.share_prefix:
+            # both halves see the same latent, timestep and image conditioning: everything before the first
+            # cross-attention (conv_in, the first ResBlock, the first self-attention) is computed once
+            pre = self.unet.cfg_prefix(xc[:b], self._half(t_buf, b, 0))
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for t in (pre.a1.buf, pre.t1.buf, pre.cat[0].buf):
+                    t.record_stream(side)
+                e1 = self.unet.forward_from_prefix(pre.branch(self.unet), cc[1])
+            e0 = self.unet.forward_from_prefix(pre, cc[0])
+            cur.wait_stream(side)
+            e1.record_stream(cur)
+            return torch.cat([e0, e1])
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             e1 = self.unet(xc[b:], timesteps=self._half(t_buf, b, 1), context=cc[1])

@@ -181,3 +181,19 @@ def test_prepare_c_concat_matches_oracle(nets):
     mean, logvar = torch.chunk(mom, 2, dim=1)
     ref = 0.18215 * (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise)
     _check(cc[:, 1:], ref.numpy(), 5e-3, 3e-3, "masked-image latents")   # measured 1.5e-3 / 8.4e-4
+
+
+def test_cfg_prefix_sharing_equals_forward(nets):
+    """Unet.cfg_prefix + forward_from_prefix (the context-free head computed once for both CFG halves) gives the bits of
+    two plain forward() calls."""
+    unet = nets[0]
+    rs = np.random.RandomState(41)
+    x = T(rs.randn(1, 9, 32, 24).astype(np.float32)).to(DEV)
+    t = torch.tensor([341], dtype=torch.long, device=DEV)
+    cu, cc = (T(rs.randn(1, 77, 1024).astype(np.float32)).to(DEV) for _ in range(2))
+    ref_u, ref_c = unet(x, timesteps=t, context=cu), unet(x, timesteps=t, context=cc)
+    pre = unet.cfg_prefix(x, t)
+    got_c = unet.forward_from_prefix(pre.branch(unet), cc)
+    got_u = unet.forward_from_prefix(pre, cu)
+    assert torch.equal(got_u, ref_u) and torch.equal(got_c, ref_c)
+    assert not torch.equal(ref_u, ref_c)
