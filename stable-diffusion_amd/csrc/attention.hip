@@ -105,8 +105,10 @@ __device__ __forceinline__ void attn_tile(const u16* sK, const u16* sV, const hx
 // grid: 1-D, nqt * heads * batch blocks; the XCD remap gives each XCD a contiguous run of (batch, head, q-tile) so
 // the K/V of the (one or two) heads an XCD is working on stay in its 4 MB L2 instead of being re-streamed by 8 XCDs.
 __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) u16 sK[2][64 * 64];  // double-buffered: one barrier per KV tile
-  __shared__ __attribute__((aligned(16))) u16 sV[2][64 * 64];
+  // double-buffered tile images, one barrier per KV tile.  Four separate arrays, and the loop below is unrolled by two
+  // so that every access names its array: the compiler then knows that a fragment read of one buffer cannot alias the
+  // LDS-DMA in flight into the other (it otherwise waits for vmcnt(0) before the first read of every tile).
+  __shared__ __attribute__((aligned(16))) u16 sK0[64 * 64], sK1[64 * 64], sV0[64 * 64], sV1[64 * 64];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hh = lane >> 5;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = bid % p.nqt, bh = bid / p.nqt;
@@ -122,32 +124,32 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const hx8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
 
-  // staging: 64 rows x 8 chunks of 16 B per tile and operand; thread -> (row = t>>3 (+32), chunk = t&7).  Full tiles
-  // advance four per-thread pointers by a constant; the last, partial tile clamps its key rows to nkv-1 (those columns
-  // of S are masked to -inf, so the duplicated rows weigh nothing): no per-load predicates in the steady state.
-  const int chunk = t & 7, r0 = t >> 3;
-  u32x4 rk0, rk1, rv0, rv1;
-  const u16 *pk0 = K + (long long)r0 * p.ldk + chunk * 8, *pk1 = pk0 + (long long)32 * p.ldk;
-  const u16 *pv0 = V + (long long)r0 * p.ldv + chunk * 8, *pv1 = pv0 + (long long)32 * p.ldv;
+  // staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land on 1 KB of consecutive LDS = 8 tile rows): wave w
+  // moves rows [16w, 16w+16) of K and of V with two instructions each; the XOR swizzle of the LDS image is applied on
+  // the SOURCE side (lane -> (row, LDS slot) -> the logical chunk that belongs in that slot).  Nothing passes through
+  // registers and no ds_write is issued.  Full tiles advance four per-thread pointers by a constant; the last,
+  // partial tile clamps its key rows to nkv-1 (those columns of S are masked to -inf, so the duplicated rows weigh
+  // nothing): no per-load predicates in the steady state.
+  const int srow0 = 16 * wv + (lane >> 3), srow1 = srow0 + 8, spos = lane & 7;
+  const int ck0 = spos ^ ((srow0 >> 1) & 7), ck1 = spos ^ ((srow1 >> 1) & 7);
+  const int cv0 = spos ^ (((srow0 >> 1) & 1) << 2), cv1 = spos ^ (((srow1 >> 1) & 1) << 2);
+  const u16 *pk0 = K + (long long)srow0 * p.ldk + ck0 * 8, *pk1 = K + (long long)srow1 * p.ldk + ck1 * 8;
+  const u16 *pv0 = V + (long long)srow0 * p.ldv + cv0 * 8, *pv1 = V + (long long)srow1 * p.ldv + cv1 * 8;
   const long long stepk = (long long)64 * p.ldk, stepv = (long long)64 * p.ldv;
-#define ATTN_LOAD_TILE(KV0)                                                                   \
+  const int wbase = __builtin_amdgcn_readfirstlane(wv) * 1024;  // elements: this wave's first 1 KB block of a tile image
+#define ATTN_GLDS(SRC, DST) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+#define ATTN_STAGE_TILE(KV0, SK, SV)                                                          \
   if ((KV0) + 64 <= p.nkv) {                                                                  \
-    rk0 = *(const u32x4*)pk0; rv0 = *(const u32x4*)pv0;                                       \
-    rk1 = *(const u32x4*)pk1; rv1 = *(const u32x4*)pv1;                                       \
+    ATTN_GLDS(pk0, &SK[wbase]); ATTN_GLDS(pv0, &SV[wbase]);                                   \
+    ATTN_GLDS(pk1, &SK[wbase + 512]); ATTN_GLDS(pv1, &SV[wbase + 512]);                       \
     pk0 += stepk; pk1 += stepk; pv0 += stepv; pv1 += stepv;                                   \
   } else {                                                                                    \
-    const int key0 = min((KV0) + r0, p.nkv - 1), key1 = min((KV0) + r0 + 32, p.nkv - 1);      \
-    rk0 = *(const u32x4*)(K + (long long)key0 * p.ldk + chunk * 8);                           \
-    rv0 = *(const u32x4*)(V + (long long)key0 * p.ldv + chunk * 8);                           \
-    rk1 = *(const u32x4*)(K + (long long)key1 * p.ldk + chunk * 8);                           \
-    rv1 = *(const u32x4*)(V + (long long)key1 * p.ldv + chunk * 8);                           \
-  }
-#define ATTN_STORE_TILE(B)                                    \
-  {                                                           \
-    *(u32x4*)&sK[B][k_off(r0, chunk)] = rk0;                  \
-    *(u32x4*)&sV[B][v_off(r0, chunk)] = rv0;                  \
-    *(u32x4*)&sK[B][k_off(r0 + 32, chunk)] = rk1;             \
-    *(u32x4*)&sV[B][v_off(r0 + 32, chunk)] = rv1;             \
+    const int key0 = min((KV0) + srow0, p.nkv - 1), key1 = min((KV0) + srow1, p.nkv - 1);     \
+    ATTN_GLDS(K + (long long)key0 * p.ldk + ck0 * 8, &SK[wbase]);                             \
+    ATTN_GLDS(V + (long long)key0 * p.ldv + cv0 * 8, &SV[wbase]);                             \
+    ATTN_GLDS(K + (long long)key1 * p.ldk + ck1 * 8, &SK[wbase + 512]);                       \
+    ATTN_GLDS(V + (long long)key1 * p.ldv + cv1 * 8, &SV[wbase + 512]);                       \
   }
 
   f32x16 oacc[2];
@@ -159,22 +161,32 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
   const int dblk = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
 
   const int ntiles = (p.nkv + 63) / 64;
-  ATTN_LOAD_TILE(0);
-  ATTN_STORE_TILE(0);
-  __syncthreads();
+  ATTN_STAGE_TILE(0, sK0, sV0);
+  __syncthreads();  // waits for this wave's DMA (vmcnt) before the barrier: tile 0 has landed for everyone
   const int nfull = p.nkv >> 6;  // full tiles run the mask-free instantiation
-  for (int tile = 0; tile < nfull; ++tile) {
-    const int kv0 = tile * 64, cur = tile & 1;
-    const bool more = tile + 1 < ntiles;
-    if (more) { ATTN_LOAD_TILE(kv0 + 64); }  // in flight over this tile's MFMAs
-    attn_tile<false>(sK[cur], sV[cur], qf, oacc, mrun, lrun, p.scale_log2, kv0, p.nkv, r, hh, dblk, tq, tp);
-    if (more) ATTN_STORE_TILE(cur ^ 1);  // the other buffer: last read in tile-1, every wave is past that barrier
-    __syncthreads();
+  // one full tile read from (CK, CV); the other buffer was last read a tile ago and every wave is past that barrier:
+  // tile+1 lands in it while this tile is computed
+#define ATTN_FULL_TILE(TILE, CK, CV, NK, NV)                                                                       \
+  {                                                                                                                \
+    const int kv0 = (TILE) * 64;                                                                                   \
+    if ((TILE) + 1 < ntiles) { ATTN_STAGE_TILE(kv0 + 64, NK, NV); }                                                \
+    attn_tile<false>(CK, CV, qf, oacc, mrun, lrun, p.scale_log2, kv0, p.nkv, r, hh, dblk, tq, tp);                 \
+    __syncthreads();                                                                                               \
   }
-  if (nfull < ntiles)  // the partial last tile (already staged by the iteration before it, or by the prologue)
-    attn_tile<true>(sK[nfull & 1], sV[nfull & 1], qf, oacc, mrun, lrun, p.scale_log2, nfull * 64, p.nkv, r, hh, dblk, tq, tp);
-#undef ATTN_LOAD_TILE
-#undef ATTN_STORE_TILE
+  int tile = 0;
+  for (; tile + 2 <= nfull; tile += 2) {
+    ATTN_FULL_TILE(tile, sK0, sV0, sK1, sV1);
+    ATTN_FULL_TILE(tile + 1, sK1, sV1, sK0, sV0);
+  }
+  if (tile < nfull) {  // odd count of full tiles: one more from buffer 0, a partial tile (if any) follows in buffer 1
+    ATTN_FULL_TILE(tile, sK0, sV0, sK1, sV1);
+    if (nfull < ntiles) attn_tile<true>(sK1, sV1, qf, oacc, mrun, lrun, p.scale_log2, nfull * 64, p.nkv, r, hh, dblk, tq, tp);
+  } else if (nfull < ntiles) {  // the partial last tile (staged by the iteration before it, or by the prologue)
+    attn_tile<true>(sK0, sV0, qf, oacc, mrun, lrun, p.scale_log2, nfull * 64, p.nkv, r, hh, dblk, tq, tp);
+  }
+#undef ATTN_FULL_TILE
+#undef ATTN_STAGE_TILE
+#undef ATTN_GLDS
 
   const float ltot = lrun + __shfl_xor(lrun, 32);
   const float inv = 1.0f / ltot;
