@@ -133,17 +133,20 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
   const int srow0 = 16 * wv + (lane >> 3), srow1 = srow0 + 8, spos = lane & 7;
   const int ck0 = spos ^ ((srow0 >> 1) & 7), ck1 = spos ^ ((srow1 >> 1) & 7);
   const int cv0 = spos ^ (((srow0 >> 1) & 1) << 2), cv1 = spos ^ (((srow1 >> 1) & 1) << 2);
-  const u16 *pk0 = K + (long long)srow0 * p.ldk + ck0 * 8, *pk1 = K + (long long)srow1 * p.ldk + ck1 * 8;
-  const u16 *pv0 = V + (long long)srow0 * p.ldv + cv0 * 8, *pv1 = V + (long long)srow1 * p.ldv + cv1 * 8;
-  const long long stepk = (long long)64 * p.ldk, stepv = (long long)64 * p.ldv;
+  // per-lane element offsets inside a tile (32-bit) + a wave-uniform tile base that advances by 64 rows: the loads
+  // address as SGPR base + VGPR offset, no vector arithmetic per tile
+  const unsigned ok0 = 2u * (srow0 * p.ldk + ck0 * 8), ok1 = 2u * (srow1 * p.ldk + ck1 * 8);  // bytes, < 2^31 (host)
+  const unsigned ov0 = 2u * (srow0 * p.ldv + cv0 * 8), ov1 = 2u * (srow1 * p.ldv + cv1 * 8);
+  const char *kt = (const char*)K, *vt = (const char*)V;
+  const long long stepk = (long long)128 * p.ldk, stepv = (long long)128 * p.ldv;  // bytes per 64-row tile
   const int wbase = __builtin_amdgcn_readfirstlane(wv) * 1024;  // elements: this wave's first 1 KB block of a tile image
 #define ATTN_GLDS(SRC, DST) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
 #define ATTN_STAGE_TILE(KV0, SK, SV)                                                          \
   if ((KV0) + 64 <= p.nkv) {                                                                  \
-    ATTN_GLDS(pk0, &SK[wbase]); ATTN_GLDS(pv0, &SV[wbase]);                                   \
-    ATTN_GLDS(pk1, &SK[wbase + 512]); ATTN_GLDS(pv1, &SV[wbase + 512]);                       \
-    pk0 += stepk; pk1 += stepk; pv0 += stepv; pv1 += stepv;                                   \
+    ATTN_GLDS(kt + ok0, &SK[wbase]); ATTN_GLDS(vt + ov0, &SV[wbase]);                         \
+    ATTN_GLDS(kt + ok1, &SK[wbase + 512]); ATTN_GLDS(vt + ov1, &SV[wbase + 512]);             \
+    kt += stepk; vt += stepv;                                                                 \
   } else {                                                                                    \
     const int key0 = min((KV0) + srow0, p.nkv - 1), key1 = min((KV0) + srow1, p.nkv - 1);     \
     ATTN_GLDS(K + (long long)key0 * p.ldk + ck0 * 8, &SK[wbase]);                             \
@@ -212,6 +215,7 @@ extern "C" int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k,
   SDMI_REQUIRE(ldq >= heads * 64 && ldk >= heads * 64 && ldv >= heads * 64 && ldo >= heads * 64, "attention: row stride < heads*64");
   SDMI_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)o & 7) == 0, "attention: pointer alignment");
   SDMI_REQUIRE(sq % 8 == 0 && sk % 8 == 0 && sv % 8 == 0 && so % 4 == 0, "attention: batch strides must keep alignment");
+  SDMI_REQUIRE(ldk < (1 << 22) && ldv < (1 << 22), "attention: k/v row stride too large");  // 32-bit in-tile byte offsets
   SDMI_REQUIRE(scale > 0.f, "attention: scale must be positive");
   SDMI_REQUIRE((long long)((nq + 127) / 128) * heads * batch < (1ll << 31), "attention: grid too large");
   AttnParams p;
