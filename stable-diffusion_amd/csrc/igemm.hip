@@ -748,37 +748,41 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(const IgemmParams p) {
   WIN_STAGE_B(1);
   WIN_WAIT();
   WIN_READ(af0, wf0, smem, 0, 0, 0);
-  int slot = 0, wsel = 0;
-  for (int kt = kt_begin; kt < kt_end; kt += 3) {
-    const u16* wcur = smem + wsel * WBUF;
-    u16* wnext = smem + (wsel ^ 1) * WBUF;
-    // kx = 0
-    WIN_READ(af1, wf1, wcur, 0, 1, slot);
-    WIN_MFMA(af0, wf0);
-    WIN_WAIT();
-    WIN_STAGE_B(slot);
-    if (kt + 3 < kt_end) WIN_STAGE_W(wnext);
-    slot ^= 1;
-    WIN_READ(af0, wf0, wcur, 1, 0, slot);
-    WIN_MFMA(af1, wf1);
-    // kx = 1
-    WIN_READ(af1, wf1, wcur, 1, 1, slot);
-    WIN_MFMA(af0, wf0);
-    WIN_WAIT();
-    WIN_STAGE_B(slot);
-    slot ^= 1;
-    WIN_READ(af0, wf0, wcur, 2, 0, slot);
-    WIN_MFMA(af1, wf1);
-    // kx = 2
-    WIN_READ(af1, wf1, wcur, 2, 1, slot);
-    WIN_MFMA(af0, wf0);
-    WIN_WAIT();
-    WIN_STAGE_B(slot);
-    slot ^= 1;
-    WIN_READ(af0, wf0, wnext, 0, 0, slot);  // first tile of the next (chunk, ky); unused after the last one
-    WIN_MFMA(af1, wf1);
-    wsel ^= 1;
+  // One (chunk, ky) group = three K-tiles (kx = 0, 1, 2) read from window WCUR, weight slots S0, S1, S0; the next
+  // group's window is staged into WNEXT during the kx = 0 step.  The loop alternates two instantiations (windows swapped,
+  // slots S0/S1 swapped) so that every LDS address is a per-lane base plus a compile-time constant.
+#define WIN_GROUP(WCUR, WNEXT, S0, S1)                                                         \
+  {                                                                                            \
+    /* kx = 0 */                                                                               \
+    WIN_READ(af1, wf1, WCUR, 0, 1, S0);                                                        \
+    WIN_MFMA(af0, wf0);                                                                        \
+    WIN_WAIT();                                                                                \
+    WIN_STAGE_B(S0);                                                                           \
+    if (kt + 3 < kt_end) WIN_STAGE_W(WNEXT);                                                   \
+    WIN_READ(af0, wf0, WCUR, 1, 0, S1);                                                        \
+    WIN_MFMA(af1, wf1);                                                                        \
+    /* kx = 1 */                                                                               \
+    WIN_READ(af1, wf1, WCUR, 1, 1, S1);                                                        \
+    WIN_MFMA(af0, wf0);                                                                        \
+    WIN_WAIT();                                                                                \
+    WIN_STAGE_B(S1);                                                                           \
+    WIN_READ(af0, wf0, WCUR, 2, 0, S0);                                                        \
+    WIN_MFMA(af1, wf1);                                                                        \
+    /* kx = 2 */                                                                               \
+    WIN_READ(af1, wf1, WCUR, 2, 1, S0);                                                        \
+    WIN_MFMA(af0, wf0);                                                                        \
+    WIN_WAIT();                                                                                \
+    WIN_STAGE_B(S0);                                                                           \
+    WIN_READ(af0, wf0, WNEXT, 0, 0, S1); /* first tile of the next group; unused after the last one */ \
+    WIN_MFMA(af1, wf1);                                                                        \
   }
+  for (int kt = kt_begin; kt < kt_end; kt += 3) {
+    WIN_GROUP(smem, smem + WBUF, 0, 1);
+    kt += 3;
+    if (kt >= kt_end) break;
+    WIN_GROUP(smem + WBUF, smem, 1, 0);
+  }
+#undef WIN_GROUP
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #undef WIN_GLDS
 #undef WIN_STAGE_W
