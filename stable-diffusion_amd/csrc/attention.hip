@@ -33,13 +33,17 @@ __device__ __forceinline__ void attn_tile(const u16* sK, const u16* sV, const hx
   f32x16 s[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+  // all eight K fragments are requested before the first MFMA needs one (the compiler otherwise reads each just in time
+  // and every MFMA of the chain waits out an LDS latency); the two accumulator chains alternate
+  hx8 kf[2][4];
 #pragma unroll
   for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const hx8 a = *(const hx8*)&sK[k_off(32 * kt2 + r, 2 * ks + hh)];
-      s[kt2] = MFMA32(a, qf[ks], s[kt2], 0, 0, 0);
-    }
+    for (int ks = 0; ks < 4; ++ks) kf[kt2][ks] = *(const hx8*)&sK[k_off(32 * kt2 + r, 2 * ks + hh)];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) s[kt2] = MFMA32(kf[kt2][ks], qf[ks], s[kt2], 0, 0, 0);
   // raw-score max (scale > 0, so max commutes with the scaling); padded keys of the last tile are excluded.  TAIL is a
   // template parameter and the partial tile is peeled out of the loop: as a run-time (even wave-uniform) condition hipcc
   // turned the mask into ~100 always-executed compare/select instructions per tile, a third of the loop's VALU work.
