@@ -182,8 +182,10 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     unet_ms = e0.elapsed_time(e1) / 10
+    sampler.decode_to_uint8(x_T, use_graph=not args.no_graph)
+    torch.cuda.synchronize()
     e0.record()
-    sampler.decode_to_uint8(x_T)
+    sampler.decode_to_uint8(x_T, use_graph=not args.no_graph)
     e1.record()
     torch.cuda.synchronize()
     dec_ms = e0.elapsed_time(e1)
