@@ -169,16 +169,16 @@ def main():
         dt = float(tt.item())
 
     # UNet step latency (graph replay of one forward, CFG batch 2b) on its own
-    xc = torch.randn((2 * b, 9, L, L), device=dev)
+    xc = torch.randn((b, 9, L, L), device=dev).repeat(2, 1, 1, 1)   # CFG: both halves see the same latent and conditioning
     tb = torch.full((2 * b,), 501, dtype=torch.long, device=dev)
     cc = sampler.make_context(uncond, cond)
     tb = unet.precompute_time_embedding(tb)   # as the sampling loop runs it: the t-only MLPs are hoisted out of the step
-    sampler._unet_step(xc, tb, cc, not args.no_graph)
+    sampler._unet_step(xc, tb, cc, not args.no_graph, same_halves=True)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        sampler._unet_step(xc, tb, cc, not args.no_graph)
+        sampler._unet_step(xc, tb, cc, not args.no_graph, same_halves=True)
     e1.record()
     torch.cuda.synchronize()
     unet_ms = e0.elapsed_time(e1) / 10

@@ -100,7 +100,7 @@ class Sampler(object):
             return TimeEmb(t_buf.table[which * b:(which + 1) * b])
         return t_buf[which * b:(which + 1) * b]
 
-    def _unet_eval(self, xc, t_buf, cc):
+    def _unet_eval(self, xc, t_buf, cc, same_halves=False):
         if not self.dual_stream:
             return self.unet(xc, timesteps=t_buf, context=cc)
         b = xc.shape[0] // 2
@@ -111,7 +111,7 @@ class Sampler(object):
             torch.cuda.synchronize()
             self._side = torch.cuda.Stream()
         side = self._side
-        if self.share_prefix:
+        if self.share_prefix and same_halves:
             # both halves see the same latent, timestep and image conditioning: everything before the first
             # cross-attention (conv_in, the first ResBlock, the first self-attention) is computed once
             pre = self.unet.cfg_prefix(xc[:b], self._half(t_buf, b, 0))
@@ -132,18 +132,20 @@ class Sampler(object):
         return torch.cat([e0, e1])
 
     # one UNet evaluation on the static buffers, eager or replayed
-    def _unet_step(self, xc, t_buf, cc, use_graph):
+    def _unet_step(self, xc, t_buf, cc, use_graph, same_halves=False):
+        """same_halves: the caller guarantees xc[:b] == xc[b:] and equal timesteps (sample() builds them that way), which
+        lets the two CFG halves share the context-free head of the UNet."""
         if not use_graph:
-            return self._unet_eval(xc, t_buf, cc)
+            return self._unet_eval(xc, t_buf, cc, same_halves)
         # the graph is valid while the buffers it read are alive and in place: key on the objects that own them (the
         # sampler keeps xc, the TimeEmb row and the ContextKV alive; a caller's own buffers must outlive the graph)
-        key = (xc.data_ptr(), t_buf.table.data_ptr() if hasattr(t_buf, "table") else t_buf.data_ptr(), id(cc), tuple(xc.shape))
+        key = (xc.data_ptr(), t_buf.table.data_ptr() if hasattr(t_buf, "table") else t_buf.data_ptr(), id(cc), tuple(xc.shape), same_halves)
         if self._gkey != key:
-            self._unet_eval(xc, t_buf, cc)                      # warm-up: weight pre-pack, allocator pools
+            self._unet_eval(xc, t_buf, cc, same_halves)         # warm-up: weight pre-pack, allocator pools
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self._unet_eval(xc, t_buf, cc)
+                out = self._unet_eval(xc, t_buf, cc, same_halves)
             self._graph, self._gout, self._gkey, self._gkeep = g, out, key, (xc, t_buf, cc)
         self._graph.replay()
         return self._gout
@@ -172,7 +174,7 @@ class Sampler(object):
         for i, step in enumerate(np.flip(ts)):
             index = total - i - 1
             emb_cur.table.copy_(emb_table[i])
-            eps = self._unet_step(xc, emb_cur, cc, use_graph)
+            eps = self._unet_step(xc, emb_cur, cc, use_graph, same_halves=True)   # xc halves are built identical above
             E.cfg_ddim_step(eps, x, noises[i], scale, _f32(s1m[index]), _f32(a_t[index]), _f32(a_prev[index]),
                             _f32(sig[index]), temperature, x_out=x, xc_out=xc)
             if trace is not None:
