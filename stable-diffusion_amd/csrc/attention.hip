@@ -1,11 +1,11 @@
-// attention.hip - fused flash-style attention forward, head_dim 64, bf16 in/out, fp32 softmax state.
+// attention.hip - fused flash-style attention forward, head_dim 64, 16-bit (fp16 / bf16 build) in/out, fp32 softmax state.
 //
 // Replaces xformers.ops.memory_efficient_attention(q,k,v) and the head split/merge copies around it
 // (layers/SpatialTransformer.py:76-95): o = softmax(q k^T * scale) v, no mask, no dropout.  q/k/v/o are
 // read and written in place as (B, tokens, heads*64) views, so nothing is permuted or made contiguous.
 //
-// Structure (gfx950): block = 4 waves, each wave owns 32 query rows; KV tiles of 64 keys are staged
-// global -> registers -> LDS (the loads of tile t+1 are in flight while tile t is computed).
+// Structure (gfx950): block = 4 waves, each wave owns 32 query rows; KV tiles of 64 keys are staged by LDS-DMA
+// (global_load_lds_dwordx4) into double-buffered tile images, tile t+1 in flight while tile t is computed.
 //   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with K rows as the A operand (ds_read_b128, XOR-swizzled rows) and
 //                 the wave's Q fragment (registers, loaded once) as B: the accumulator then has the QUERY on
 //                 the lane and the keys in registers, so the online softmax (row max / sum) is lane-local
