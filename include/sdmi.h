@@ -76,6 +76,16 @@ int sdmi_groupnorm_apply(const void* x, int ldx, const float* scale_shift, void*
 int sdmi_groupnorm(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups, const float* gamma,
                    const float* beta, float eps, uint32_t flags, float* scale_shift, void* ws, void* stream);
 
+/* ---- GroupNorm(+SiLU) that allocates nothing.  NO counterpart in the reference: it exists for callers that cannot
+ *      allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ *      Same arithmetic and bits as sdmi_groupnorm; the scale/shift table and the partial sums live in a static device
+ *      array of sdmi_groupnorm_static_max_bytes() (1 MiB) per GPU instead of caller-provided buffers.  Shapes that need
+ *      more (n*c*8 rounded up to 256 + sdmi_groupnorm_ws_bytes(n, hw, c) bytes) are rejected with SDMI_EINVAL.  Calls on
+ *      one GPU share that array: calls that overlap in time on one GPU (different streams) race. */
+int sdmi_groupnorm_static(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups, const float* gamma,
+                          const float* beta, float eps, uint32_t flags, void* stream);
+int64_t sdmi_groupnorm_static_max_bytes(void);
+
 /* ---- LayerNorm: nn.LayerNorm at layers/SpatialTransformer.py:177-184 ----------------------- */
 int sdmi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
                    int rows, int c, void* stream);

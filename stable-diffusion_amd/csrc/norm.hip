@@ -454,6 +454,49 @@ extern "C" int sdmi_groupnorm(const void* x, int ldx, void* y, int ldy, int n, i
   return sdmi_groupnorm_apply(x, ldx, scale_shift, y, ldy, n, hw, c, flags, stream);
 }
 
+// ------------------------------------------------------------------------------------ GroupNorm without allocations
+// sdmi_groupnorm for callers that cannot allocate (HIP graph capture, tight serving loops): the per-(sample, channel)
+// scale/shift table and the per-block partial sums, which sdmi_groupnorm takes as caller-allocated buffers, live in a
+// file-scope device array.  Every GPU the library runs on holds its own copy at its own address, resolved once per
+// device by hipGetSymbolAddress.  All calls on one GPU share the array: calls that overlap in time on one GPU race.
+// Nothing has to start at zero (every word that is read was written earlier in the same call).
+constexpr size_t GN_STATIC_BYTES = 1u << 20;
+static __device__ __align__(256) unsigned char scratch[GN_STATIC_BYTES];
+
+static unsigned char* gn_static_ptr() {
+  static unsigned char* ptr_of_device[64] = {};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    sdmi_set_error("groupnorm_static: hipGetDevice failed or device index %d >= 64", dev);
+    return nullptr;
+  }
+  if (!ptr_of_device[dev]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      sdmi_set_error("groupnorm_static: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
+      return nullptr;
+    }
+    ptr_of_device[dev] = (unsigned char*)ptr;
+  }
+  return ptr_of_device[dev];
+}
+
+extern "C" int64_t sdmi_groupnorm_static_max_bytes(void) { return (int64_t)GN_STATIC_BYTES; }
+
+extern "C" int sdmi_groupnorm_static(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups,
+                                     const float* gamma, const float* beta, float eps, uint32_t flags, void* stream) {
+  SDMI_REQUIRE(n > 0 && hw > 0 && c > 0, "groupnorm_static: bad shape n=%d hw=%d c=%d", n, hw, c);
+  const int64_t ss_bytes = ((int64_t)n * c * 2 * (int64_t)sizeof(float) + 255) / 256 * 256;
+  const int64_t need = ss_bytes + sdmi_groupnorm_ws_bytes(n, hw, c);
+  SDMI_REQUIRE(need <= (int64_t)GN_STATIC_BYTES,
+               "groupnorm_static: n=%d hw=%d c=%d needs %lld bytes of scratch, the static buffer holds %lld: use sdmi_groupnorm "
+               "with caller-allocated buffers", n, hw, c, (long long)need, (long long)GN_STATIC_BYTES);
+  unsigned char* ptr = gn_static_ptr();
+  if (!ptr) return SDMI_ELAUNCH;
+  return sdmi_groupnorm(x, ldx, y, ldy, n, hw, c, groups, gamma, beta, eps, flags, (float*)ptr, ptr + ss_bytes, stream);
+}
+
 // ------------------------------------------------------------------------------------ LayerNorm
 // one wave per row, the row lives in registers (two-pass mean / variance like torch).
 template <int NS>
