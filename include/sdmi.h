@@ -125,7 +125,7 @@ int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, 
 
 /* tuning hook (benchmarks only; no reference counterpart): force the tile variant (index into the kernel's variant table,
  * 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64) and / or the split-K factor of every following
- * sdmi_conv3x3 / sdmi_gemm call of this process; -1 = automatic (the default). */
+ * sdmi_conv3x3 / sdmi_gemm call of the calling host thread (thread-local, like the error state); -1 = automatic (the default). */
 void sdmi_tune_override(int tile, int splits);
 /* tuning hook: 0 = run stride-1 3x3 convolutions on the generic im2col kernel, 1 = on the shared-window kernel (same bits,
  * fewer bytes staged), -1 = automatic (default: shared window wherever it applies, env SDMI_CONV_WIN=0 turns it off). */

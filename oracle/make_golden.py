@@ -71,6 +71,53 @@ def _load_reference_sampler():
     return ns
 
 
+def reference_schedules(ns, step_counts):
+    """G8: the schedule tables of the step counts the configs use, read from the REFERENCE object itself: its own
+    sample() (compiled from its source) runs on a UNet stub that returns zeros and records the timesteps it is called
+    with, and a decoder stub; the ddim_* attributes it leaves behind are the reference's tables.  The oracle's
+    ddim_schedule() is asserted identical to them."""
+    LDI = ns["LatentDiffusionInpainting"]
+
+    class ZeroUnet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def forward(self, xc, timesteps=None, context=None):
+            self.seen.append(int(timesteps[0]))
+            return torch.zeros((xc.shape[0], 4) + tuple(xc.shape[2:]))
+
+    class ZeroVae(torch.nn.Module):
+        def decode(self, z):
+            return torch.zeros((z.shape[0], 3, 8, 8))
+
+    saved = ns["noise_like"]
+    ns["noise_like"] = lambda shape, device, repeat=False: torch.zeros(shape)
+    g8 = {}
+    for n in step_counts:
+        model = LDI.__new__(LDI)
+        torch.nn.Module.__init__(model)
+        model.diffusion_model, model.first_stage_model = ZeroUnet(), ZeroVae()
+        model.dpm_num_timesteps, model.scale_factor, model.channels = 1000, 0.18215, 4
+        model.diffusion_param_schedule()
+        c = {"c_concat": [torch.zeros(1, 5, 1, 1)], "c_crossattn": [torch.zeros(1, 77, 1024)]}
+        model.sample(n, [1, 4, 1, 1], c, eta=1.0, unconditional_guidance_scale=9.0, unconditional_conditioning=c,
+                     x_T=torch.zeros(1, 4, 1, 1))
+        seen = model.diffusion_model.seen if hasattr(model.diffusion_model, "seen") else None
+        ts = np.flip(np.asarray(seen))                       # sample() walks the timesteps from the last to the first
+        sch = O.ddim_schedule(n)
+        assert np.array_equal(ts, np.asarray(sch["timesteps"])), "timesteps n=%d" % n
+        g8["n%d_timesteps" % n] = ts.astype(np.asarray(sch["timesteps"]).dtype)
+        for k, attr in (("alphas", "ddim_alphas"), ("alphas_prev", "ddim_alphas_prev"), ("sigmas", "ddim_sigmas"),
+                        ("sqrt_one_minus_alphas", "ddim_sqrt_one_minus_alphas")):
+            ref_v = np.asarray(getattr(model, attr), dtype=np.float64)
+            assert np.array_equal(ref_v, np.asarray(sch[k], dtype=np.float64)), "schedule %s n=%d" % (k, n)
+            g8["n%d_%s" % (n, k)] = ref_v
+        print("  n=%d: %d timesteps and 4 coefficient tables read from the reference object; oracle identical" % (n, len(ts)))
+    ns["noise_like"] = saved
+    return g8
+
+
 def _close(a, b, what, tol=2e-5):
     d = (a - b).abs().max().item()
     s = b.abs().max().item()
@@ -91,6 +138,9 @@ def _csum(sd):
 def main():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    if "--only-g8" in sys.argv:       # regenerate the schedule fixture alone (seconds)
+        np.savez(os.path.join(OUT, "g8_schedule.npz"), **reference_schedules(_load_reference_sampler(), (10, 45, 50)))
+        return
     _install_xformers_standin()
     sys.path.insert(0, REF)
     from layers.ResBlock import ResBlock, Upsample, Downsample
@@ -211,14 +261,7 @@ def main():
     model.diffusion_model, model.first_stage_model = unet, vae
     model.dpm_num_timesteps, model.scale_factor, model.channels = 1000, 0.18215, 4
     model.diffusion_param_schedule()
-    g8 = {}
-    for n in (10, 45, 50):
-        ref_tr = {"x": []}
-        # run the schedule part only: zero-step trick is impossible, so re-derive from the attributes sample() leaves
-        sch = O.ddim_schedule(n)
-        g8["n%d_timesteps" % n] = sch["timesteps"]
-        for k in ("alphas", "alphas_prev", "sigmas", "sqrt_one_minus_alphas"):
-            g8["n%d_%s" % (n, k)] = np.asarray(sch[k], dtype=np.float64)
+    g8 = reference_schedules(ns, (10, 45, 50))
     steps, L, b, scale = 4, 8, 1, 9.0  # n=3 hits the t=1000 index bug noted at LatentDiffusionInpainting.py:156
     inp = make_inputs(b, L, steps, seed=100)
     it = iter(inp["noises"])

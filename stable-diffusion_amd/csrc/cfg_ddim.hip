@@ -4,11 +4,11 @@
 // operation order, so with identical inputs the result is bit-identical to the torch expression chain.
 #include "common.h"
 
-__global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__ eps, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__ eps, const float* x,
                                                        const float* __restrict__ noise, float guidance, float s1m,
                                                        float sqrt_at, float sqrt_aprev, float dir_coef, float sigma,
-                                                       float temperature, float* __restrict__ x_out,
-                                                       float* __restrict__ pred_x0, float* __restrict__ xc_out,
+                                                       float temperature, float* x_out,
+                                                       float* pred_x0, float* xc_out,
                                                        int xc_channels, int b, int chw) {
   const long long total = (long long)b * chw;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {

@@ -798,14 +798,15 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(const IgemmParams p) {
 // produces the same bits whether it runs alone or inside a larger batch (the image-sharded multi-GPU path relies on
 // it).  Under-filled grids (few output tiles, long K) are cut so that >= ~384 blocks exist per sample.
 // tuning override (sdmi_tune_override): -1 = automatic
-static int g_force_tile = -1, g_force_splits = -1, g_force_window = -1;
+// (thread-local like the error state: a tuning or profiling call on one host thread never changes another thread's launches)
+static thread_local int g_force_tile = -1, g_force_splits = -1, g_force_window = -1;
 extern "C" void sdmi_tune_override(int tile, int splits) { g_force_tile = tile; g_force_splits = splits; }
 extern "C" void sdmi_tune_conv_window(int on) { g_force_window = on; }
 
 // Profiling aid (bench.py's roofline pass): an event the next split-K launch records on its stream BETWEEN the main
 // kernel and the fixed-order reduce kernel, so that a caller bracketing the entry point with two events of its own can
 // price the two kernels apart.  One-shot: cleared by the launch that uses it (and by passing NULL).
-static hipEvent_t g_mid_event = nullptr;
+static thread_local hipEvent_t g_mid_event = nullptr;
 extern "C" void sdmi_prof_mid_event(void* ev) { g_mid_event = (hipEvent_t)ev; }
 static void record_mid_event(hipStream_t st) {
   if (g_mid_event) { (void)hipEventRecord(g_mid_event, st); g_mid_event = nullptr; }
@@ -952,8 +953,8 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   // Opt-in (SDMI_SPLITK_INKERNEL=1): bit-identical to the reduce kernel, but measured SLOWER on the UNet step (10.9 ms
   // against 10.3: the reducing block's serial read of every partial tile plus write-through stores cost more than the
   // 7-13 us reduce launch they replace; with a release fence instead of write-through stores 11.5 ms).
-  const char* inkernel = getenv("SDMI_SPLITK_INKERNEL");
-  if (p.splits > 1 && (long long)nb * batch <= SK_TICKET_TILES && inkernel && inkernel[0] == '1') {
+  static const bool inkernel = [] { const char* e = getenv("SDMI_SPLITK_INKERNEL"); return e && e[0] == '1'; }();
+  if (p.splits > 1 && (long long)nb * batch <= SK_TICKET_TILES && inkernel) {
     static void* sym_of_device[64] = {};  // every device holds its own copy of the array at its own address
     int dev = 0;
     (void)hipGetDevice(&dev);

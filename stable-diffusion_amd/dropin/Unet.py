@@ -133,10 +133,16 @@ class Unet(nn.Module):
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None):
+        return self.forward_into(x, timesteps, context, None)
+
+    @torch.no_grad()
+    def forward_into(self, x, timesteps, context, eps_out):
+        """forward() whose last conv writes into `eps_out`, a contiguous fp32 (n, 4, h, w) tensor (e.g. one half of a
+        sampler's CFG noise-prediction buffer), instead of a new tensor."""
         if isinstance(context, list):
             context = context[0]
         st = self._begin(x, timesteps)
-        return self._finish(st, context)
+        return self._finish(st, context, eps_out)
 
     @torch.no_grad()
     def cfg_prefix(self, x, timesteps):
@@ -153,10 +159,12 @@ class Unet(nn.Module):
         return st
 
     @torch.no_grad()
-    def forward_from_prefix(self, st, context):
+    def forward_from_prefix(self, st, context, eps_out=None):
+        """eps_out: optional contiguous fp32 (n, 4, h, w) tensor (e.g. one half of a CFG eps buffer) the last conv
+        writes into directly."""
         if isinstance(context, list):
             context = context[0]
-        return self._finish(st, context)
+        return self._finish(st, context, eps_out)
 
     def _begin(self, x, timesteps):
         """Geometry, the concat buffers of the skip connections, the timestep-embedding table and conv_in."""
@@ -165,6 +173,8 @@ class Unet(nn.Module):
         dev = x.device
         st = _FwdState()
         st.keep, st.emb, st.ldrb = self._emb_pointers(timesteps.table if isinstance(timesteps, TimeEmb) else self._embeddings(timesteps))
+        if st.keep.shape[0] != n:
+            raise E.L.SdmiError("Unet.forward: %d timesteps for a batch of %d" % (st.keep.shape[0], n))
         st.n, st.dev = n, dev
 
         # ---- geometry + concat plan: skip k is consumed by output block (K-1-k) next to an `h` of cat_c1[k] channels
@@ -202,8 +212,13 @@ class Unet(nn.Module):
             cat[k] = E.new_act(st.n, sh, sw, c1 + st.skip_c[k], st.dev)
         return cat
 
-    def _finish(self, st, context):
+    def _finish(self, st, context, eps_out=None):
+        if context is None:
+            raise E.L.SdmiError("Unet.forward: context=None - every cross-attention's to_k / to_v is Linear(1024, inner) and "
+                                "cannot project the tokens themselves (the reference fails in to_k for the same call)")
         ctx = context if isinstance(context, ContextKV) else self.precompute_context(context)
+        if ctx._shape[0] != st.n:
+            raise E.L.SdmiError("Unet.forward: context holds %d samples, x holds %d" % (ctx._shape[0], st.n))
         emb, ldrb, cat, skip_c = st.emb, st.ldrb, st.cat, st.skip_c
         nin = len(self.input_blocks)
         c1_of = lambda k: cat[k].c - skip_c[k]
@@ -231,7 +246,7 @@ class Unet(nn.Module):
             h = self._run_stage(blk, cat[k], emb, ldrb, ctx, dst)
         gn, conv = self.out[0], self.out[2]
         h = E.groupnorm(h, gn.weight, gn.bias, gn.eps, silu=True)
-        return E.conv3x3(h, conv.weight, conv.bias, out_nchw=True)
+        return E.conv3x3(h, conv.weight, conv.bias, out_nchw=eps_out if eps_out is not None else True)
 
 
 class _FwdState(object):

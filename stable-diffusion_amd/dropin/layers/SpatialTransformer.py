@@ -103,6 +103,9 @@ class MemoryEfficientCrossAttention(nn.Module):
     def run(self, a, context=None, residual=None):
         inner = 64 * self.heads
         if context is None:          # self-attention: one fused q|k|v GEMM
+            if self.to_k.weight.shape[1] != a.c:
+                raise E.L.SdmiError("attention without context: to_k expects %d channels, the tokens have %d (the reference "
+                                    "fails in to_k as well)" % (self.to_k.weight.shape[1], a.c))
             qkv = E.gemm(a, E.packed_linear((self.to_q.weight, self.to_k.weight, self.to_v.weight)), 3 * inner)
             q, k, v = qkv.cols(0, inner), qkv.cols(inner, inner), qkv.cols(2 * inner, inner)
         else:

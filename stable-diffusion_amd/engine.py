@@ -160,6 +160,7 @@ def stacked_f32(params):
 
 # --------------------------------------------------------------------------- split-K workspace
 _WS = {}
+_WS_RETIRED = []
 
 
 def _workspace(device, nbytes):
@@ -170,9 +171,20 @@ def _workspace(device, nbytes):
     key = (device, torch.cuda.current_stream(device).cuda_stream)   # concurrent streams must not share partials
     t = _WS.get(key)
     if t is None or t.numel() * 4 < nbytes:
+        if t is not None:
+            _WS_RETIRED.append(t)       # a captured HIP graph may still address it: never freed (sizes double, so the
+            nbytes = max(nbytes, 2 * t.numel() * 4)   # retired buffers add up to less than the live one)
         t = torch.empty(((max(nbytes, 64 << 20) + 3) // 4,), dtype=torch.float32, device=device)
         _WS[key] = t
     return t.data_ptr(), t.numel() * 4
+
+
+def _check_out(res, n, h, w, c, what):
+    """A caller-supplied `out=` view must have exactly the shape the op produces: the kernels write n*h*w rows of c
+    channels into it unchecked (the reference raises at torch.cat for the same mismatch, Unet.py:132)."""
+    if (res.n, res.h, res.w, res.c) != (n, h, w, c):
+        raise L.SdmiError("%s: `out` is (n=%d, h=%d, w=%d, c=%d) but the result is (n=%d, h=%d, w=%d, c=%d)" %
+                          (what, res.n, res.h, res.w, res.c, n, h, w, c))
 
 
 # --------------------------------------------------------------------------- ops
@@ -223,12 +235,19 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
         flags |= L.F_OUT_U8_IMAGE
         res = torch.empty((a.n, ho, wo, cout), dtype=torch.uint8, device=a.device)
         optr, ldc = res.data_ptr(), 0
-    elif out_nchw:
+    elif out_nchw is not False and out_nchw is not None:
         flags |= L.F_OUT_NCHW_F32
-        res = torch.empty((a.n, cout, ho, wo), dtype=torch.float32, device=a.device)
+        if out_nchw is True:
+            res = torch.empty((a.n, cout, ho, wo), dtype=torch.float32, device=a.device)
+        else:                           # a caller's fp32 NCHW tensor (e.g. one half of a CFG eps buffer)
+            res = out_nchw
+            if tuple(res.shape) != (a.n, cout, ho, wo) or res.dtype != torch.float32 or not res.is_contiguous():
+                raise L.SdmiError("conv3x3: out_nchw tensor must be contiguous fp32 %s, got %s %s" %
+                                  ((a.n, cout, ho, wo), tuple(res.shape), res.dtype))
         optr, ldc = res.data_ptr(), 0
     else:
         res = out if out is not None else new_act(a.n, ho, wo, cout, a.device)
+        _check_out(res, a.n, ho, wo, cout, "conv3x3")
         optr, ldc = res.ptr, res.ld
     ws, wsb = _workspace(a.device, L.load().sdmi_conv3x3_ws_bytes(a.n, cin, cout, ho, wo))
     L.call("sdmi_conv3x3", a.ptr, a.ld, a.n, a.h, a.w, cin, wp.data_ptr(), cout, ho, wo, stride, pt, pl,
@@ -241,6 +260,8 @@ def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shap
     m = a.n * a.hw
     cres = n_out // 2 if geglu else n_out
     res = out if out is not None else new_act(a.n, a.h, a.w, cres, a.device)
+    if (res.n * res.hw, res.c) != (m, cres):
+        raise L.SdmiError("gemm: `out` holds %d rows x %d channels, the product has %d x %d" % (res.n * res.hw, res.c, m, cres))
     flags = 0
     if bias is not None:
         flags |= L.F_BIAS
@@ -259,6 +280,9 @@ def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shap
 def attention(q, k, v, heads, out=None):
     """softmax(q k^T / 8) v per head; q/k/v are column views (Act.cols) of token buffers."""
     o = out if out is not None else new_act(q.n, q.h, q.w, heads * 64, q.device)
+    if (o.n, o.hw, o.c) != (q.n, q.hw, heads * 64) or (k.n, v.n, v.hw) != (q.n, q.n, k.hw):
+        raise L.SdmiError("attention: q (%d,%d) / k (%d,%d) / v (%d,%d) / out (%d,%d,%d) do not match" %
+                          (q.n, q.hw, k.n, k.hw, v.n, v.hw, o.n, o.hw, o.c))
     L.call("sdmi_attention", q.ptr, q.ld, q.hw * q.ld, k.ptr, k.ld, k.hw * k.ld, v.ptr, v.ld, v.hw * v.ld,
            o.ptr, o.ld, o.hw * o.ld, q.n, heads, q.hw, k.hw, 0.125, _stream())
     return o
@@ -266,11 +290,13 @@ def attention(q, k, v, heads, out=None):
 
 def linear_small_m(x, wp, bias, silu_in=False):
     """fp32 (M<=64, K) x bf16 [N][K] -> fp32 (M, N)."""
+    x = x.contiguous()
     m, k = x.shape
     n = wp.shape[0]
     out = torch.empty((m, n), dtype=torch.float32, device=x.device)
-    L.call("sdmi_linear_small_m", x.data_ptr(), wp.data_ptr(), _ptr(bias), out.data_ptr(), m, n, k,
-           L.F_SILU if silu_in else 0, _stream())
+    for m0 in range(0, m, 64):      # the kernel takes at most 64 rows per launch (larger CFG batches: several launches)
+        L.call("sdmi_linear_small_m", x.data_ptr() + 4 * m0 * k, wp.data_ptr(), _ptr(bias), out.data_ptr() + 4 * m0 * n,
+               min(64, m - m0), n, k, L.F_SILU if silu_in else 0, _stream())
     return out
 
 

@@ -53,9 +53,14 @@ class Sampler(object):
         # both the same latent / timestep / image conditioning): compute it once per step.  SDMI_SHARE_PREFIX=0: A/B.
         self.share_prefix = os.environ.get("SDMI_SHARE_PREFIX", "1") == "1"
 
+    @staticmethod
+    def weights_signature(module):
+        """(storage, version) of every parameter: changes on load_state_dict / in-place updates / .to(device).  Captured
+        graphs and cached tables are keyed on it, so they are rebuilt instead of replaying stale packed weights."""
+        return tuple((p.data_ptr(), p._version) for p in module.parameters()) if module is not None else ()
+
     def _time_tables(self, steps, bc, dev):
-        w = self.unet.time_embed[0].weight
-        key = (tuple(int(s) for s in steps), bc, str(dev), w.data_ptr(), w._version)
+        key = (tuple(int(s) for s in steps), bc, str(dev), self._usig)
         if getattr(self, "_tt_key", None) != key:
             t_buf = torch.empty((bc,), dtype=torch.long, device=dev)
             rows = []
@@ -100,10 +105,19 @@ class Sampler(object):
             return TimeEmb(t_buf.table[which * b:(which + 1) * b])
         return t_buf[which * b:(which + 1) * b]
 
+    def _eps_buffer(self, xc):
+        """(2b, 4, h, w) fp32 noise-prediction buffer [uncond | cond]: each CFG half's last conv writes its half."""
+        shape = (xc.shape[0], 4, xc.shape[2], xc.shape[3])
+        eps = getattr(self, "_eps", None)
+        if eps is None or tuple(eps.shape) != shape or eps.device != xc.device:
+            self._eps = eps = torch.empty(shape, dtype=torch.float32, device=xc.device)
+        return eps
+
     def _unet_eval(self, xc, t_buf, cc, same_halves=False):
         if not self.dual_stream:
             return self.unet(xc, timesteps=t_buf, context=cc)
         b = xc.shape[0] // 2
+        eps = self._eps_buffer(xc)
         cur = torch.cuda.current_stream()
         if self._side is None:
             # first use: one pass on the current stream fills the weight pre-pack cache (shared by both streams)
@@ -119,17 +133,16 @@ class Sampler(object):
             with torch.cuda.stream(side):
                 for t in (pre.a1.buf, pre.t1.buf, pre.cat[0].buf):
                     t.record_stream(side)
-                e1 = self.unet.forward_from_prefix(pre.branch(self.unet), cc[1])
-            e0 = self.unet.forward_from_prefix(pre, cc[0])
+                self.unet.forward_from_prefix(pre.branch(self.unet), cc[1], eps_out=eps[b:])
+            self.unet.forward_from_prefix(pre, cc[0], eps_out=eps[:b])
             cur.wait_stream(side)
-            e1.record_stream(cur)
-            return torch.cat([e0, e1])
+            return eps
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            e1 = self.unet(xc[b:], timesteps=self._half(t_buf, b, 1), context=cc[1])
-        e0 = self.unet(xc[:b], timesteps=self._half(t_buf, b, 0), context=cc[0])
+            self.unet.forward_into(xc[b:], self._half(t_buf, b, 1), cc[1], eps[b:])
+        self.unet.forward_into(xc[:b], self._half(t_buf, b, 0), cc[0], eps[:b])
         cur.wait_stream(side)
-        return torch.cat([e0, e1])
+        return eps
 
     # one UNet evaluation on the static buffers, eager or replayed
     def _unet_step(self, xc, t_buf, cc, use_graph, same_halves=False):
@@ -139,7 +152,8 @@ class Sampler(object):
             return self._unet_eval(xc, t_buf, cc, same_halves)
         # the graph is valid while the buffers it read are alive and in place: key on the objects that own them (the
         # sampler keeps xc, the TimeEmb row and the ContextKV alive; a caller's own buffers must outlive the graph)
-        key = (xc.data_ptr(), t_buf.table.data_ptr() if hasattr(t_buf, "table") else t_buf.data_ptr(), id(cc), tuple(xc.shape), same_halves)
+        key = (xc.data_ptr(), t_buf.table.data_ptr() if hasattr(t_buf, "table") else t_buf.data_ptr(), id(cc), tuple(xc.shape), same_halves,
+               getattr(self, "_usig", None) or self.weights_signature(self.unet))
         if self._gkey != key:
             self._unet_eval(xc, t_buf, cc, same_halves)         # warm-up: weight pre-pack, allocator pools
             torch.cuda.synchronize()
@@ -157,6 +171,7 @@ class Sampler(object):
         all fp32 cuda tensors.  Returns (latent, uint8 images (b,H,W,3) or None)."""
         ts, a_t, a_prev, sig, s1m = ddim_schedule(num_ddim_timesteps, eta)
         total = ts.shape[0]
+        self._usig = self.weights_signature(self.unet)      # once per image: keys the captured step and the cached tables
         b, _, h, w = x_T.shape
         dev = x_T.device
         xc = self._static_xc((2 * b, 4 + c_concat.shape[1], h, w), dev)
@@ -202,7 +217,7 @@ class Sampler(object):
         the image out of one, so the call stays re-entrant for the caller."""
         if not use_graph:
             return self.vae.decode_image_u8(1. / SCALE_FACTOR * latent)
-        key = (tuple(latent.shape), str(latent.device))
+        key = (tuple(latent.shape), str(latent.device), self.weights_signature(self.vae))
         if getattr(self, "_dkey", None) != key:
             self._din = torch.empty_like(latent, dtype=torch.float32)
             self._din.copy_(latent)

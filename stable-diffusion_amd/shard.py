@@ -24,9 +24,9 @@ def shard_inputs(inputs, rank, world):
 
 def all_gather_images(local, total, group=None):
     """Gather per-rank (b_local, ...) uint8 tensors into (total, ...) on every rank, in image order."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local
+    world = dist.get_world_size(group)      # a one-rank group still goes through the collective (same code path as N ranks)
     rank = dist.get_rank(group)
     sizes = [shard_bounds(total, r, world) for r in range(world)]
     bmax = max(hi - lo for lo, hi in sizes)
