@@ -123,6 +123,57 @@ int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_
               int64_t ws_bytes, void* stream);
 int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags);
 
+/* ---- epilogue extensions of sdmi_gemm / sdmi_conv3x3 (sdmi_gemm_ex / sdmi_conv3x3_ex; ext = NULL gives the plain calls).
+ *      They move the reference's normalisation passes into the kernels on either side of them:
+ *      - colstats: the producing conv / GEMM also writes per-channel (sum, sum of squares) of its fp32 results over each
+ *        wave tile's rows, fp32 [row_parts][N][2] (fixed order, no atomics); sdmi_groupnorm_from_colstats folds them, so the
+ *        GroupNorm that follows (layers/ResBlock.py:65,:72; layers/SpatialTransformer.py:212) never re-reads the tensor for
+ *        its statistics.
+ *      - rowstats: the producing GEMM also writes per-row (sum, sum of squares) over each column part, fp32
+ *        [M][col_parts][2], for a LayerNorm that follows (layers/SpatialTransformer.py:182-184).
+ *      - SDMI_F_LNFOLD: this GEMM consumes such row statistics and computes LayerNorm(x) @ W^T without a LayerNorm pass:
+ *        w was packed by sdmi_pack_linear_ln (gamma folded into the weights), the epilogue applies
+ *        out = rstd[m] * (acc - mean[m] * ln_u[n]) + bias[n], bias = the ln_v of sdmi_pack_linear_ln.
+ *      sdmi_*_stats_parts tell how many parts a problem writes (0 = it cannot: split-K, odd shapes); asking for statistics
+ *      a launch cannot deliver is an error, never a silent skip. */
+#define SDMI_F_LNFOLD 512u
+typedef struct sdmi_epilogue_ext {
+  float* colstats;          /* out, or NULL */
+  float* rowstats;          /* out, or NULL */
+  const float* ln_rowstats; /* SDMI_F_LNFOLD: [M][ln_parts][2] written by the producer of the GEMM's input */
+  const float* ln_u;        /* SDMI_F_LNFOLD: [N] in packed row order (sdmi_pack_linear_ln) */
+  int ln_parts;
+  float ln_eps;
+} sdmi_epilogue_ext;
+int sdmi_gemm_ex(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
+                 int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
+                 int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* ws,
+                 int64_t ws_bytes, void* stream, const sdmi_epilogue_ext* ext);
+int sdmi_conv3x3_ex(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout,
+                    int hout, int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias,
+                    int ldrb, const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* ws, int64_t ws_bytes,
+                    void* stream, const sdmi_epilogue_ext* ext);
+/* parts of the statistics the calls above write for this problem: *row_parts (colstats) and *col_parts (rowstats); 0 where
+ * the problem cannot emit them.  Either pointer may be NULL.  (upsample: SDMI_F_UPSAMPLE2X in flags) */
+int sdmi_gemm_stats_parts(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags, int* row_parts, int* col_parts);
+int sdmi_conv3x3_stats_parts(int n, int h, int w, int cin, int cout, int hout, int wout, int stride, int pad_t, int pad_l,
+                             uint32_t flags, int* row_parts);
+/* GroupNorm(+SiLU) whose statistics come from colstats written by the producer(s) of x (parts of 32 rows).  Up to two
+ * channel segments, in channel order (a skip-connection concat, Unet.py:132, has two producers and a group may straddle
+ * them): segment s covers channels [seg_c0[s], seg_c0[s] + seg_c[s]) of x; seg_stats[s] is the producer's array
+ * [sample * seg_parts[s] + part][seg_ld[s]][2] (seg_parts = row parts PER SAMPLE = hw / 32, seg_ld = the producer's N) and
+ * the segment's channels start at column seg_col0[s] of it.  scale_shift: scratch of sdmi_groupnorm_colstats_ss_bytes(). */
+int64_t sdmi_groupnorm_colstats_ss_bytes(int n, int c, int groups);
+int sdmi_groupnorm_from_colstats(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups,
+                                 const float* gamma, const float* beta, float eps, uint32_t flags, int nseg,
+                                 const float* const* seg_stats, const int* seg_parts, const int* seg_ld, const int* seg_col0,
+                                 const int* seg_c0, const int* seg_c, float* scale_shift, void* stream);
+/* nn.Linear weight with a LayerNorm folded in (layers/SpatialTransformer.py:182-184 feeding :62-66 / :22-26):
+ * w_packed[n][k] = h16(gamma[k] * w[n][k]) (geglu: rows interleaved as sdmi_pack_linear does), u[n] = sum_k w_packed[n][k]
+ * (fp32, packed row order), v[n] = sum_k beta[k] * w[n][k] + bias[n] (original row order, like a bias; bias may be NULL). */
+int sdmi_pack_linear_ln(const float* w, const float* gamma, const float* beta, const float* bias, void* w_packed, float* u,
+                        float* v, int n, int k, int geglu, void* stream);
+
 /* tuning hook (benchmarks only; no reference counterpart): force the tile variant (index into the kernel's variant table,
  * 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64) and / or the split-K factor of every following
  * sdmi_conv3x3 / sdmi_gemm call of the calling host thread (thread-local, like the error state); -1 = automatic (the default). */
@@ -130,6 +181,10 @@ void sdmi_tune_override(int tile, int splits);
 /* tuning hook: 0 = run stride-1 3x3 convolutions on the generic im2col kernel, 1 = on the shared-window kernel (same bits,
  * fewer bytes staged), -1 = automatic (default: shared window wherever it applies, env SDMI_CONV_WIN=0 turns it off). */
 void sdmi_tune_conv_window(int on);
+
+/* experiment switch for A/B measurements inside one process (no reference counterpart; defaults are the shipped
+ * behaviour): "gemm_small_m_tile", "attn_variant".  Unknown names return SDMI_EINVAL. */
+int sdmi_set_option(const char* name, int value);
 
 /* Profiling aid, no counterpart in the reference: `event` (a hipEvent_t, or NULL to clear) is recorded by the NEXT
  * sdmi_gemm / sdmi_conv3x3 call that splits K, on that call's stream, between its main kernel and its fixed-order

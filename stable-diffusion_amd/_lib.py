@@ -11,6 +11,14 @@ LIB_PATH = os.environ.get("SDMI_LIB_PATH") or os.path.join(_HERE, "libsdmi355.so
 
 # flags (sdmi.h)
 F_BIAS, F_ROWBIAS, F_RESIDUAL, F_GEGLU, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_SILU, F_OUT_F32, F_OUT_U8_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128, 256
+F_LNFOLD = 512
+
+
+class EpilogueExt(C.Structure):
+    """sdmi_epilogue_ext (include/sdmi.h)."""
+    _fields_ = [("colstats", C.c_void_p), ("rowstats", C.c_void_p), ("ln_rowstats", C.c_void_p), ("ln_u", C.c_void_p),
+                ("ln_parts", C.c_int), ("ln_eps", C.c_float)]
+
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
@@ -37,9 +45,17 @@ PROTOTYPES = {
     "sdmi_conv3x3_in": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "sdmi_gemm": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp, _i64, _vp]),
     "sdmi_gemm_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _u32]),
+    "sdmi_gemm_ex": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp, _i64, _vp, _vp]),
+    "sdmi_conv3x3_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp, _i64, _vp, _vp]),
+    "sdmi_gemm_stats_parts": (_i, [_i, _i, _i, _i, _i, _u32, _vp, _vp]),
+    "sdmi_conv3x3_stats_parts": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u32, _vp]),
+    "sdmi_groupnorm_from_colstats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdmi_groupnorm_colstats_ss_bytes": (_i64, [_i, _i, _i]),
+    "sdmi_pack_linear_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sdmi_tune_override": (None, [_i, _i]),
     "sdmi_tune_conv_window": (None, [_i]),
     "sdmi_prof_mid_event": (None, [_vp]),
+    "sdmi_set_option": (_i, [C.c_char_p, _i]),
     "sdmi_probe_mfma": (_i, [_vp, _i, _i, _vp]),
     "sdmi_probe_copy": (_i, [_vp, _vp, _i64, _vp]),
     "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
@@ -112,7 +128,7 @@ def call(name, *args):
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         mid = None
-        if name in ("sdmi_conv3x3", "sdmi_gemm"):
+        if name in ("sdmi_conv3x3", "sdmi_gemm", "sdmi_conv3x3_ex", "sdmi_gemm_ex"):
             # a split-K launch records this event between its main kernel and its fixed-order reduce kernel
             mid = torch.cuda.Event(enable_timing=True)
             mid.record(st)                      # creates the handle; the library records it again if it splits K

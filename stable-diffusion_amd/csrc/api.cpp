@@ -38,3 +38,23 @@ extern "C" int sdmi_act_dtype(void) { return 1; }
 extern "C" int sdmi_act_dtype(void) { return 0; }
 #endif
 extern "C" const char* sdmi_last_error(void) { return g_err; }
+
+// Runtime experiment switches (benchmarks / A-B runs only; defaults are the shipped behaviour).  A tiny name -> int table
+// read by the launch paths: lets one process time two code paths interleaved (scratch/ab_step.py) instead of comparing
+// runs on different boxes.
+#include <string.h>
+static struct { const char* name; int value; } g_options[] = {
+    {"gemm_small_m_tile", 1},   // 1: 64x64 tiles for K >= 2048 GEMMs with fewer than 1024 rows (0: 64x128 as in round 1)
+    {"attn_variant", 0},        // attention kernel variant (0 = default)
+};
+int sdmi_option(const char* name) {
+  for (auto& o : g_options)
+    if (!strcmp(o.name, name)) return o.value;
+  return 0;
+}
+extern "C" int sdmi_set_option(const char* name, int value) {
+  for (auto& o : g_options)
+    if (!strcmp(o.name, name)) { o.value = value; return SDMI_OK; }
+  sdmi_set_error("sdmi_set_option: unknown option '%s'", name);
+  return SDMI_EINVAL;
+}

@@ -30,6 +30,7 @@ typedef h16 hx2 __attribute__((ext_vector_type(2)));
 void sdmi_set_error(const char* fmt, ...);
 int sdmi_check_launch(const char* what);
 void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the last entry point launched
+int sdmi_option(const char* name);           // runtime experiment switch (api.cpp; sdmi_set_option)
 
 #define SDMI_REQUIRE(cond, ...)            \
   do {                                     \

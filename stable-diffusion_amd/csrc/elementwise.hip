@@ -103,6 +103,45 @@ extern "C" int sdmi_pack_linear(const float* w, void* w_packed, int n, int k, in
   return sdmi_check_launch("pack_linear");
 }
 
+// LayerNorm folded into the Linear that follows it: one wave per packed row.  w'[n][k] = h16(gamma[k] w[n][k]); u[row] = the
+// fp32 sum of the ROUNDED packed row (what the MFMA sums when every input element equals the row mean); v[n] = beta . w[n] + b[n].
+__global__ __launch_bounds__(256) void pack_linear_ln_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             u16* __restrict__ o, float* __restrict__ u, float* __restrict__ v,
+                                                             int n, int k, int geglu) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // packed row
+  if (row >= n) return;
+  int srow = row;
+  if (geglu) {
+    const int b = row >> 5, s = (row >> 4) & 1, j = row & 15;
+    srow = (s ? (n >> 1) : 0) + 16 * b + j;
+  }
+  const float* wr = w + (long long)srow * k;
+  float su = 0.f, sv = 0.f;
+  for (int kk = lane; kk < k; kk += 64) {
+    const float wv = wr[kk];
+    const u16 h = f2h(gamma[kk] * wv);
+    o[(long long)row * k + kk] = h;
+    su += h2f(h);
+    sv += beta[kk] * wv;
+  }
+  su = wave_sum(su);
+  sv = wave_sum(sv);
+  if (lane == 0) {
+    u[row] = su;
+    v[srow] = sv + (bias ? bias[srow] : 0.f);
+  }
+}
+extern "C" int sdmi_pack_linear_ln(const float* w, const float* gamma, const float* beta, const float* bias, void* w_packed, float* u,
+                                   float* v, int n, int k, int geglu, void* stream) {
+  SDMI_REQUIRE(w && gamma && beta && w_packed && u && v && n > 0 && k > 0, "pack_linear_ln: bad argument");
+  SDMI_REQUIRE(!geglu || n % 32 == 0, "pack_linear_ln: geglu needs n%%32==0 (n=%d)", n);
+  hipLaunchKernelGGL(pack_linear_ln_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, bias, (u16*)w_packed, u, v,
+                     n, k, geglu);
+  return sdmi_check_launch("pack_linear_ln");
+}
+
 // ------------------------------------------------------------------------------------ first conv (tiny Cin)
 // x NCHW fp32 (the caller's tensor), w OIHW fp32, out NHWC h16.  lane = pixel (64 consecutive pixels per wave: coalesced
 // NCHW reads), wave = group of 8 output channels: the weight index is wave-uniform, so the 8 x 9*CIN weights arrive

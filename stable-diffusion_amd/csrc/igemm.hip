@@ -37,6 +37,13 @@ struct IgemmParams {
   unsigned* ticket;  // split-K: per-tile arrival counters (in-kernel reduction by the last arriver); null = reduce kernel
   int nmajor;    // tile order: consecutive tile ids walk M first (an XCD's run of tiles shares weight panels)
   int fast_epi;  // host-checked: shapes / alignments allow the LDS-transposed 16-byte epilogue
+  // epilogue extensions (sdmi_epilogue_ext): statistics for the normalisation that follows / a LayerNorm folded in
+  float* colstats;         // [row part][N][2]: per-channel (sum, sumsq) over each wave tile's rows
+  float* rowstats;         // [M][col_parts][2]: per-row (sum, sumsq) over each wave tile's columns
+  const float* ln_stats;   // LNFOLD: [M][ln_parts][2] row partials of the input
+  const float* ln_u;       // LNFOLD: [N] column sums of the packed weights
+  int ln_parts, col_parts;
+  float ln_eps;
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};  // non-const: stays in the global address space (no flat loads)
@@ -202,13 +209,38 @@ __device__ __forceinline__ void epi_prefetch(const IgemmParams& p, EpiRegs<TM, T
   }
 }
 
-template <int TM, int TN, bool GEGLU>
+// s += v, q += v * v as two plain VALU instructions.  Inline asm on purpose: left to the SLP vectoriser these sums became
+// v_pk_mul_f32 / v_pk_add_f32 chains with op_sel half swaps, and on MI355X such a chain rarely (about 1 result in 10^4, not
+// reproducible run to run) lost one element's square while the plain sum beside it stayed exact.
+__device__ __forceinline__ void stat_acc(float& s, float& q, float v) {
+  float t;
+  asm("v_mul_f32 %2, %3, %3\n\tv_add_f32 %1, %1, %2\n\tv_add_f32 %0, %0, %3" : "+v"(s), "+v"(q), "=&v"(t) : "v"(v));
+}
+
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4): every lane ends up with the row's total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+typedef const float __attribute__((address_space(3)))* lds_cfp;
+// lnside: LDS side region of an LNFOLD launch: float2 (mean, rstd) per tile row, then the tile's BN column sums u; lrow0 /
+// lcol0 = this wave's first row / column inside the block tile; spart / cpart = index of the wave tile's first 32-row part /
+// 32-column part
+template <int TM, int TN, bool GEGLU, bool LNC, bool CS>
 __device__ __forceinline__ void epi_finish(const IgemmParams& p, const EpiRegs<TM, TN, GEGLU>& r,
-                                           f32x4 (&acc)[TM / 16][TN / 16], int bz, int row0, int col0, int lane) {
+                                           f32x4 (&acc)[TM / 16][TN / 16], int bz, int row0, int col0, int lane,
+                                           lds_cfp lnside, int ln_bm, int lrow0, int lcol0, int spart, int cpart) {
   using R = EpiRegs<TM, TN, GEGLU>;
   const uint32_t fl = p.flags;
   const int l15 = lane & 15;
   const bool odd = (lane >> 4) & 1;
+  const bool lnf = LNC && (fl & SDMI_F_LNFOLD) != 0;  // LNC = false (convolutions): the LayerNorm fold and the row statistics
+  const bool cstat = CS && p.colstats != nullptr;     // compile away; CS = false: so do the column statistics
+  const lds_cfp lnu = lnside + 2 * ln_bm;
   const int nout = GEGLU ? p.N >> 1 : p.N;
   const int hwo = p.rows_per_sample;
   // rows of a second sample inside this tile (host guarantees rows_per_sample >= BM: at most two samples): their
@@ -233,9 +265,39 @@ __device__ __forceinline__ void epi_finish(const IgemmParams& p, const EpiRegs<T
       }
     }
   }
+  // LNFOLD: the 8 column sums u of each chunk this lane finishes (non-GEGLU; GEGLU: of every 16-column tile, MFMA layout),
+  // from the LDS side region
+  f32x4 gu[GEGLU ? R::NT : 1];
+  if constexpr (GEGLU) {
+#pragma unroll
+    for (int j = 0; j < R::NT; ++j)
+      gu[j] = lnf ? *(const f32x4 __attribute__((address_space(3)))*)(lnu + lcol0 + j * 16 + (lane >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    gu[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 lu[R::NP][2];
+  float csum[R::NP][8], csq[R::NP][8];  // colstats: per-channel sums over this wave tile's rows
+#pragma unroll
+  for (int pr = 0; pr < R::NP; ++pr) {
+    lu[pr][0] = lu[pr][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!GEGLU) {
+      if (lnf) {
+        const int lc = lcol0 + (2 * pr + ((lane >> 4) & 1)) * 16 + (lane >> 5) * 8;
+        lu[pr][0] = *(const f32x4 __attribute__((address_space(3)))*)(lnu + lc);
+        lu[pr][1] = *(const f32x4 __attribute__((address_space(3)))*)(lnu + lc + 4);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[pr][e] = csq[pr][e] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < R::MT; ++i) {
     const int m = row0 + i * 16 + l15;
+    float2 st = make_float2(0.f, 1.f);  // LNFOLD: (mean, rstd) of row m
+    if (lnf) {
+      const lds_cfp sp = lnside + 2 * (lrow0 + i * 16 + l15);
+      st = make_float2(sp[0], sp[1]);
+    }
     float y[R::NP][8];
 #pragma unroll
     for (int pr = 0; pr < R::NP; ++pr) {
@@ -243,8 +305,10 @@ __device__ __forceinline__ void epi_finish(const IgemmParams& p, const EpiRegs<T
       if constexpr (GEGLU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float xa = acc[i][4 * pr][e] * p.alpha + r.gb[4 * pr][e], ga = acc[i][4 * pr + 1][e] * p.alpha + r.gb[4 * pr + 1][e];
-          const float xb = acc[i][4 * pr + 2][e] * p.alpha + r.gb[4 * pr + 2][e], gb = acc[i][4 * pr + 3][e] * p.alpha + r.gb[4 * pr + 3][e];
+          const float xa = (acc[i][4 * pr][e] * p.alpha - st.x * gu[4 * pr][e]) * st.y + r.gb[4 * pr][e];
+          const float ga = (acc[i][4 * pr + 1][e] * p.alpha - st.x * gu[4 * pr + 1][e]) * st.y + r.gb[4 * pr + 1][e];
+          const float xb = (acc[i][4 * pr + 2][e] * p.alpha - st.x * gu[4 * pr + 2][e]) * st.y + r.gb[4 * pr + 2][e];
+          const float gb = (acc[i][4 * pr + 3][e] * p.alpha - st.x * gu[4 * pr + 3][e]) * st.y + r.gb[4 * pr + 3][e];
           va[e] = xa * gelu_erf(ga);
           vb[e] = xb * gelu_erf(gb);
         }
@@ -267,8 +331,49 @@ __device__ __forceinline__ void epi_finish(const IgemmParams& p, const EpiRegs<T
         unpack2(rv[0], q[0], q[1]); unpack2(rv[1], q[2], q[3]); unpack2(rv[2], q[4], q[5]); unpack2(rv[3], q[6], q[7]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          y[pr][e] = ((y[pr][e] * p.alpha + r.bia[pr][0][e]) + rs0[e]) + q[e];
-          y[pr][e + 4] = ((y[pr][e + 4] * p.alpha + r.bia[pr][1][e]) + rs1[e]) + q[e + 4];
+          // (mean 0, rstd 1, u 0 without LNFOLD: the subtraction and the product change no bit)
+          y[pr][e] = ((((y[pr][e] * p.alpha - st.x * lu[pr][0][e]) * st.y) + r.bia[pr][0][e]) + rs0[e]) + q[e];
+          y[pr][e + 4] = ((((y[pr][e + 4] * p.alpha - st.x * lu[pr][1][e]) * st.y) + r.bia[pr][1][e]) + rs1[e]) + q[e + 4];
+        }
+      }
+    }
+    if constexpr (!GEGLU) {
+      if (LNC && p.rowstats) {
+        // per-row (sum, sumsq) of this wave tile's columns: in-lane over the lane's chunks, then over the 4 lanes that
+        // share the row (lane ^ 16, lane ^ 32); fixed order
+        // one part per 32 columns (= per tile pair), whatever the tile shape: the parts, and with them the LayerNorm
+        // that sums them, do not depend on the variant the launch picked (batch invariance)
+#pragma unroll
+        for (int pr = 0; pr < R::NP; ++pr) {
+          float rs_ = 0.f, rq_ = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) stat_acc(rs_, rq_, y[pr][e]);
+          rs_ += __shfl_xor(rs_, 16); rq_ += __shfl_xor(rq_, 16);
+          rs_ += __shfl_xor(rs_, 32); rq_ += __shfl_xor(rq_, 32);
+          if ((lane >> 4) == 0 && m < p.M && cpart + pr < p.col_parts)
+            *(float2*)(p.rowstats + ((long long)m * p.col_parts + cpart + pr) * 2) = make_float2(rs_, rq_);
+        }
+      }
+      if (cstat) {
+#pragma unroll
+        for (int pr = 0; pr < R::NP; ++pr)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) stat_acc(csum[pr][e], csq[pr][e], y[pr][e]);
+        if (i & 1) {
+          // one part per 32 rows, whatever the tile shape (batch invariance, as for the row statistics): fold the 16
+          // rows held by the lanes of a DPP row; lane 0 of each row stores its chunk's 8 x (sum, sumsq)
+#pragma unroll
+          for (int pr = 0; pr < R::NP; ++pr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { csum[pr][e] = row16_sum(csum[pr][e]); csq[pr][e] = row16_sum(csq[pr][e]); }
+            if (l15 == 0 && cvalid[pr]) {
+              float* o = p.colstats + ((long long)(spart + (i >> 1)) * p.N + ocol[pr]) * 2;
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) *(f32x4*)(o + 2 * e) = f32x4{csum[pr][e], csq[pr][e], csum[pr][e + 1], csq[pr][e + 1]};
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[pr][e] = csq[pr][e] = 0.f;
+          }
         }
       }
     }
@@ -311,10 +416,11 @@ __device__ __forceinline__ void epi_finish(const IgemmParams& p, const EpiRegs<T
 
 // Everything after the K loop, shared by the GEMM / generic-conv kernel and the shared-window conv kernel: split-K partials
 // (+ optional in-launch reduction) and the epilogue.  row0 / col0 = first output row / column of this wave's tile.
-template <int TM, int TN, bool GEGLU>
+template <int TM, int TN, bool GEGLU, bool LNC, bool CS>
 __device__ __forceinline__ void igemm_finish(const IgemmParams& p, f32x4 (&acc)[TM / 16][TN / 16],
                                              EpiRegs<TM, (!GEGLU || TN >= 64) ? TN : 64, GEGLU>& er, bool fast, u16* smem, int bz,
-                                             int row0, int col0) {
+                                             int row0, int col0, lds_cfp lnside, int ln_bm, int lrow0, int lcol0, int spart,
+                                             int cpart) {
   constexpr int MT = TM / 16, NT = TN / 16;
   constexpr bool FAST_OK = !GEGLU || TN >= 64;
   const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, lq = lane >> 4;
@@ -376,7 +482,7 @@ __device__ __forceinline__ void igemm_finish(const IgemmParams& p, f32x4 (&acc)[
     }
   }
   if constexpr (FAST_OK) if (fast) {
-    epi_finish<TM, TN, GEGLU>(p, er, acc, bz, row0, col0, lane);
+    epi_finish<TM, TN, GEGLU, LNC, CS>(p, er, acc, bz, row0, col0, lane, lnside, ln_bm, lrow0, lcol0, spart, cpart);
     return;
   }
 #pragma unroll
@@ -547,13 +653,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 #define IGEMM_WAIT_STAGE(GROUPS)                                                                    \
   {                                                                                                 \
     constexpr int INFLIGHT = (GROUPS) * (PA + PB);                                                  \
-    if constexpr (INFLIGHT == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
-    else if constexpr (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   \
-    else if constexpr (INFLIGHT == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   \
-    else if constexpr (INFLIGHT == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   \
-    else if constexpr (INFLIGHT == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); \
-    else if constexpr (INFLIGHT == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); \
-    else static_assert(INFLIGHT < 0, "add a vmcnt literal for this configuration");                 \
+    static_assert(INFLIGHT >= 0 && INFLIGHT < 64, "vmcnt is a 6-bit counter");                     \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");                      \
     __builtin_amdgcn_s_barrier();                                                                   \
   }
 
@@ -588,6 +689,63 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
   if constexpr (FAST_OK) if (fast && p.splits == 1) epi_prefetch<TM, TN, GEGLU>(p, er, bz, brow + wr * TM, bcol + wc * TN, lane);
 #pragma unroll
   for (int sidx = 0; sidx < NSTAGE; ++sidx) IGEMM_STAGE_TILE(kt_begin + sidx, sidx);
+  // LayerNorm folded into this GEMM (SDMI_F_LNFOLD): per-row (mean, rstd) from the producer's row partials and this tile's
+  // column sums u go to a side region of the LDS, behind the ring (same array: one LDS object).  Placed AFTER the prologue's
+  // DMA issue: the loads' latency then overlaps the wait for the first K-tile (in front of it, it delayed the whole
+  // pipeline by a memory round trip: +2...5 us on the 5-K-tile GEMMs).  Each row's partials are split over the NTH / BM
+  // threads that share it and combined by shuffles; the first barrier publishes the region.
+  float* const lnside = (float*)(smem + NSTAGE * STAGE);
+  if constexpr (!CONV) {
+    if (p.ln_stats) {
+      {
+        constexpr int TPR = NTH / BM;  // threads per tile row (2 or 4, neighbouring lanes)
+        const int lrow = t / TPR, sub = t % TPR;
+        const int row = min(brow + lrow, p.M - 1);
+        const float2* sp = (const float2*)p.ln_stats + (long long)row * p.ln_parts;
+        // fixed summation order for every tile shape: four interleaved accumulators a_j = sum of parts j, j+4, j+8, ...,
+        // total = (a0 + a1) + (a2 + a3).  A thread owns the accumulators j = sub, sub + TPR, ...
+        constexpr int NA = 4 / TPR;
+        static_assert(TPR == 2 || TPR == 4, "two or four threads per tile row");
+        float a0[NA], a1[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) a0[j] = a1[j] = 0.f;
+        // six rounds of loads (24 parts = 768 channels) in flight at once: a second, dependent batch of loads would put
+        // another memory round trip in front of every block's K loop
+        constexpr int ROUNDS = 6;
+        for (int pp = 0; pp < p.ln_parts; pp += 4 * ROUNDS) {
+          float2 v[ROUNDS][NA];
+#pragma unroll
+          for (int rr = 0; rr < ROUNDS; ++rr)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+              const int q = pp + 4 * rr + sub + j * TPR;
+              v[rr][j] = q < p.ln_parts ? sp[q] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+          for (int rr = 0; rr < ROUNDS; ++rr)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) { a0[j] += v[rr][j].x; a1[j] += v[rr][j].y; }
+        }
+        // lanes sub ^ 1 hold the odd accumulators: (a0 + a1), (a2 + a3), then their sum
+        float s0, s1;
+        if constexpr (TPR == 4) {
+          s0 = a0[0] + __shfl_xor(a0[0], 1); s1 = a1[0] + __shfl_xor(a1[0], 1);
+          s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
+        } else {
+          const float b0 = a0[0] + __shfl_xor(a0[0], 1), b1 = a1[0] + __shfl_xor(a1[0], 1);   // a0 + a1
+          const float c0 = a0[1] + __shfl_xor(a0[1], 1), c1 = a1[1] + __shfl_xor(a1[1], 1);   // a2 + a3
+          s0 = b0 + c0; s1 = b1 + c1;
+        }
+        if (sub == 0) {
+          const float inv = 1.0f / (float)p.K;
+          const float mean = s0 * inv;
+          const float var = fmaxf(s1 * inv - mean * mean, 0.f);
+          ((float2*)lnside)[lrow] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+        }
+      }
+      for (int c = t; c < BN; c += NTH) lnside[2 * BM + c] = bcol + c < p.N ? p.ln_u[bcol + c] : 0.f;
+    }
+  }
   IGEMM_WAIT_STAGE(NSTAGE - 1);  // tile kt_begin has landed, NSTAGE-1 younger ones are in flight
   IGEMM_READ_FRAGS(af0, wf0, 0, 0);
   int slot = 0;
@@ -609,7 +767,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 #undef IGEMM_WAIT_STAGE
 #undef IGEMM_GLDS
 
-  igemm_finish<TM, TN, GEGLU>(p, acc, er, fast, smem, bz, brow + wr * TM, bcol + wc * TN);
+  igemm_finish<TM, TN, GEGLU, !CONV, true>(p, acc, er, fast, smem, bz, brow + wr * TM, bcol + wc * TN, (lds_cfp)lnside, BM, wr * TM, wc * TN,
+                              (brow + wr * TM) / 32, (bcol + wc * TN) / 32);
 }
 
 // ------------------------------------------------------------------------------------------ shared-window 3x3 conv
@@ -622,7 +781,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 // is precomputed per lane, no work in the loop).  K-tile order (chunk, ky, kx) and all arithmetic are those of the
 // generic kernel, so both produce the same bits.  4 waves (2 x 2), two window buffers + a two-slot weight ring:
 // 66 KB (BN = 128) or 50 KB (BN = 64) of LDS, 2 - 3 blocks per CU.
-template <int BM, int BN>
+// CS: the epilogue can emit per-channel statistics (colstats); a separate instantiation because the 128 x 128 tile sits at
+// the 256-register budget and the statistics' accumulators push it into spills.
+template <int BM, int BN, bool CS>
 __global__ __launch_bounds__(256, 2) void conv_win_kernel(const IgemmParams p) {
   constexpr int TM = BM / 2, TN = BN / 2, MT = TM / 16, NT = TN / 16;
   constexpr int WROWS = BM + 8;           // staged window rows: BM + 2 are read; whole 8-row DMA instructions
@@ -790,7 +951,8 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(const IgemmParams p) {
 #undef WIN_WAIT
 #undef WIN_READ
 #undef WIN_MFMA
-  igemm_finish<TM, TN, false>(p, acc, er, fast, smem, 0, brow + wr * TM, bcol + wc * TN);
+  igemm_finish<TM, TN, false, false, CS>(p, acc, er, fast, smem, 0, brow + wr * TM, bcol + wc * TN, (lds_cfp)smem, 0, 0, 0, (brow + wr * TM) / 32,
+                              (bcol + wc * TN) / 32);
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -813,7 +975,7 @@ static void record_mid_event(hipStream_t st) {
 }
 
 static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags, bool conv) {
-  if (flags & SDMI_F_GEGLU) return 1;
+  if (flags & (SDMI_F_GEGLU | SDMI_F_LNFOLD)) return 1;
   if (g_force_splits > 0) return g_force_splits > nk ? nk : g_force_splits;
   static int target = -1;
   if (target < 0) {
@@ -856,11 +1018,17 @@ static const TileVariant kVariants[] = {
     {128, 64, 2, 2, 2},   // 2: 48 KB, 3 blocks / CU
     {64, 128, 2, 2, 3},   // 3
     {64, 64, 2, 2, 3},    // 4
+    // deeper rings for the latency-bound plain GEMMs (5 - 20 K-tiles; a K-tile costs one L2 round trip / tiles in flight)
+    {64, 64, 2, 2, 5},    // 5: 80 KB, 2 blocks / CU, 4 K-tiles in flight
+    {128, 64, 2, 2, 3},   // 6: 72 KB, 2 blocks / CU
+    {64, 128, 2, 2, 4},   // 7: 96 KB, 1 block / CU
 };
 
 template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, bool GEGLU>
 static void launch_variant2(dim3 grid, hipStream_t st, const IgemmParams& p) {
-  constexpr int bytes = NSTAGE * (BM + BN) * BK * 2;
+  constexpr int ring = NSTAGE * (BM + BN) * BK * 2;
+  constexpr int side = CONV ? 0 : BM * 8 + BN * 4;  // LNFOLD: (mean, rstd) per tile row + column sums, behind the ring
+  constexpr int bytes = ring + side;
   auto kfn = igemm_kernel<BM, BN, WM, WN, CONV, NSTAGE, GEGLU>;
   static unsigned long long attr_done = 0;  // per device: > 64 KB of dynamic LDS has to be allowed once
   int dev = 0;
@@ -869,7 +1037,7 @@ static void launch_variant2(dim3 grid, hipStream_t st, const IgemmParams& p) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     attr_done |= 1ull << (dev & 63);
   }
-  hipLaunchKernelGGL(kfn, grid, dim3(64 * WM * WN), bytes, st, p);
+  hipLaunchKernelGGL(kfn, grid, dim3(64 * WM * WN), p.ln_stats ? bytes : ring, st, p);
 }
 template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE>
 static void launch_variant(dim3 grid, hipStream_t st, const IgemmParams& p) {
@@ -897,9 +1065,12 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
     // traffic there).  From the sweep of the UNet's shapes, scratch/tune_sweep.py.
     const long long b2 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * batch * p.splits;
     if (b2 >= 600) return 2;
-    if (p.K >= 2048 && p.N >= 1024) return 3;
+    // (64 x 128 only with enough rows: at M = 576 / 144, one CFG half of the 24x24 / 12x12 levels, 64 x 64 ran 1.1 - 1.6x
+    // faster on the K >= 2048 GEMMs: scratch/gemm_sweep_b1.py)
+    if (p.K >= 2048 && p.N >= 1024 && (p.M >= 1024 || !sdmi_option("gemm_small_m_tile"))) return 3;
     return 4;
   }
+  if (!conv && p.M <= 256) return 3;  // GEGLU on a 12x12 level: 64-row tiles (144 rows in 128-row tiles compute 256)
   const bool bn128 = (p.N % 128 == 0) || (p.N > 512);
   const int bn = bn128 ? 128 : 64;
   const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * batch * p.splits;
@@ -914,23 +1085,56 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   return 4;
 }
 
+// Split-K factor and tile variant of a problem (no launch): shared by the launch path and the sdmi_*_stats_parts queries.
 template <bool CONV>
-static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+static int plan_igemm(IgemmParams& p, int batch, bool have_ws, int64_t ws_bytes) {
   p.splits = 1;
   p.kt_per_split = p.nk;
   p.npad = (p.N + 3) / 4 * 4;
-  p.ws = nullptr;
   const int s = splitk_factor(p.rows_per_sample, p.N, p.nk, p.flags, CONV);
-  if (s >= 2 && ws && ws_bytes >= splitk_ws_bytes(p.M, p.N, p.nk, batch, p.rows_per_sample, p.flags, CONV)) {
+  if (s >= 2 && have_ws && ws_bytes >= splitk_ws_bytes(p.M, p.N, p.nk, batch, p.rows_per_sample, p.flags, CONV)) {
     p.kt_per_split = (p.nk + s - 1) / s;
     if (CONV) p.kt_per_split = (p.kt_per_split + 2) / 3 * 3;  // whole (chunk, ky) groups: the shared-window kernel needs it
     p.splits = (p.nk + p.kt_per_split - 1) / p.kt_per_split;
-    p.ws = (float*)ws;
   }
-  const int vi = choose_variant(p, batch, CONV);
+  return choose_variant(p, batch, CONV);
+}
+// row parts (colstats) / column parts (rowstats) a planned launch writes; 0 = it cannot emit them
+static void stats_parts_of(const IgemmParams& p, int batch, int vi, int* row_parts, int* col_parts) {
+  // parts are 32 rows / 32 columns whatever the tile variant: what a consumer sums does not depend on the variant, and so
+  // not on the batch (the variant choice looks at the whole grid)
+  const TileVariant& tv = kVariants[vi];
+  const int tm = tv.bm / tv.wm, tn = tv.bn / tv.wn;
+  const bool plain = p.splits == 1 && batch == 1 && p.N % 8 == 0 &&
+                     !(p.flags & (SDMI_F_GEGLU | SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE | SDMI_F_OUT_F32)) && tn >= 32 && tm >= 32;
+  if (row_parts) *row_parts = (plain && p.M % tm == 0 && p.rows_per_sample % 32 == 0) ? p.M / 32 : 0;
+  if (col_parts) *col_parts = (plain && p.N % 32 == 0) ? p.N / 32 : 0;
+}
+
+template <bool CONV>
+static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st, const sdmi_epilogue_ext* ext = nullptr) {
+  p.ws = nullptr;
+  const int vi = plan_igemm<CONV>(p, batch, ws != nullptr, ws_bytes);
+  if (p.splits > 1) p.ws = (float*)ws;
   const TileVariant& tv = kVariants[vi];
   const int bm = tv.bm, bn = tv.bn;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+  p.colstats = nullptr; p.rowstats = nullptr; p.ln_stats = nullptr; p.ln_u = nullptr; p.ln_parts = 0; p.col_parts = 0; p.ln_eps = 0.f;
+  if (ext) {
+    int rparts = 0, cparts = 0;
+    stats_parts_of(p, batch, vi, &rparts, &cparts);
+    SDMI_REQUIRE(!ext->colstats || rparts > 0, "%s: this problem cannot emit colstats (ask sdmi_*_stats_parts first)", CONV ? "conv3x3" : "gemm");
+    SDMI_REQUIRE(!ext->rowstats || cparts > 0, "%s: this problem cannot emit rowstats (ask sdmi_*_stats_parts first)", CONV ? "conv3x3" : "gemm");
+    SDMI_REQUIRE((((uintptr_t)ext->colstats | (uintptr_t)ext->rowstats) & 15) == 0, "epilogue ext: statistics buffers must be 16-byte aligned");
+    p.colstats = ext->colstats; p.rowstats = ext->rowstats; p.col_parts = cparts;
+    if (p.flags & SDMI_F_LNFOLD) {
+      SDMI_REQUIRE(!CONV && ext->ln_rowstats && ext->ln_u && ext->ln_parts > 0 && ext->ln_eps > 0.f, "gemm: SDMI_F_LNFOLD needs ln_rowstats, ln_u, ln_parts, ln_eps");
+      SDMI_REQUIRE(batch == 1 && p.splits == 1 && !(p.flags & (SDMI_F_ROWBIAS | SDMI_F_OUT_NCHW_F32)), "gemm: SDMI_F_LNFOLD with batch / split-K / rowbias / NCHW output");
+      SDMI_REQUIRE((((uintptr_t)ext->ln_rowstats) & 7) == 0 && (((uintptr_t)ext->ln_u) & 3) == 0, "gemm: LNFOLD alignment");
+      p.ln_stats = ext->ln_rowstats; p.ln_u = ext->ln_u; p.ln_parts = ext->ln_parts; p.ln_eps = ext->ln_eps;
+    }
+  }
+  SDMI_REQUIRE(!(p.flags & SDMI_F_LNFOLD) || p.ln_stats, "gemm: SDMI_F_LNFOLD without an epilogue ext");
   {
     const uint32_t fl = p.flags;
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -940,6 +1144,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     if (fl & SDMI_F_ROWBIAS) fast = fast && al16(p.rowbias) && p.ldrb % 4 == 0 && p.rows_per_sample >= bm;
     if (fl & SDMI_F_RESIDUAL) fast = fast && al16(p.res) && p.ldr % 8 == 0;
     p.fast_epi = fast ? 1 : 0;
+    SDMI_REQUIRE(fast || !(p.colstats || p.rowstats || p.ln_stats), "%s: statistics / LNFOLD need the 16-byte epilogue (alignment of out / bias / residual, N %% 8)", CONV ? "conv3x3" : "gemm");
   }
   // the XCD remap gives every XCD (private L2) a contiguous run of tile ids: order the ids so that the run shares the
   // LARGER operand's panels - weight panels when N > M (the 24x24 / 12x12 levels: 29-59 MB of weights against 1-3 MB of
@@ -979,12 +1184,15 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!((attr_done >> (dev & 63)) & 1ull)) {
-          (void)hipFuncSetAttribute((const void*)conv_win_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
+          (void)hipFuncSetAttribute((const void*)conv_win_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
+          (void)hipFuncSetAttribute((const void*)conv_win_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
           attr_done |= 1ull << (dev & 63);
         }
-        hipLaunchKernelGGL((conv_win_kernel<128, 128>), grid, dim3(256), wbytes128, st, p);
+        if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 128, true>), grid, dim3(256), wbytes128, st, p);
+        else hipLaunchKernelGGL((conv_win_kernel<128, 128, false>), grid, dim3(256), wbytes128, st, p);
       } else {
-        hipLaunchKernelGGL((conv_win_kernel<128, 64>), grid, dim3(256), wbytes64, st, p);
+        if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 64, true>), grid, dim3(256), wbytes64, st, p);
+        else hipLaunchKernelGGL((conv_win_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);
       }
       sdmi_note_kernel("conv_win_kernel<128, %d>%s", bn, (p.splits > 1 && !p.ticket) ? " + igemm_splitk_reduce_kernel" : "");
       int rcw = sdmi_check_launch("conv3x3 (shared window)");
@@ -1002,7 +1210,17 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     case 1: launch_variant<128, 128, 2, 2, CONV, 2>(grid, st, p); break;
     case 2: launch_variant<128, 64, 2, 2, CONV, 2>(grid, st, p); break;
     case 3: launch_variant<64, 128, 2, 2, CONV, 3>(grid, st, p); break;
-    default: launch_variant<64, 64, 2, 2, CONV, 3>(grid, st, p); break;
+    case 4: launch_variant<64, 64, 2, 2, CONV, 3>(grid, st, p); break;
+    default:
+      if constexpr (!CONV) {  // GEMM-only variants
+        if (vi == 5) launch_variant<64, 64, 2, 2, false, 5>(grid, st, p);
+        else if (vi == 6) launch_variant<128, 64, 2, 2, false, 3>(grid, st, p);
+        else launch_variant<64, 128, 2, 2, false, 4>(grid, st, p);
+      } else {
+        sdmi_set_error("conv3x3: tile variant %d is GEMM-only", vi);
+        return SDMI_EINVAL;
+      }
+      break;
   }
   sdmi_note_kernel("igemm_kernel<%d, %d, %d, %d, %s, %d, %s>%s", bm, bn, tv.wm, tv.wn, CONV ? "true" : "false", tv.nstage,
                    (p.flags & SDMI_F_GEGLU) ? "true" : "false", (p.splits > 1 && !p.ticket) ? " + igemm_splitk_reduce_kernel" : "");
@@ -1018,10 +1236,30 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+static int gemm_params(IgemmParams& p, const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
+                       int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias, int ldrb,
+                       int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags) {
+  p = IgemmParams{};
+  p.a = (const u16*)a; p.w = (const u16*)w; p.out = out; p.bias = bias; p.rowbias = rowbias; p.res = (const u16*)residual;
+  p.sa = sa; p.sw = sw; p.sc = sc; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
+  p.M = m; p.N = n; p.K = k; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : m; p.alpha = alpha; p.flags = flags;
+  p.nk = (k + BK - 1) / BK;
+  p.kt_per_tap = 1;
+  return 0;
+}
+
 extern "C" int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
                          int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
                          int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* ws,
                          int64_t ws_bytes, void* stream) {
+  return sdmi_gemm_ex(a, lda, sa, w, ldw, sw, out, ldc, sc, m, n, k, batch, bias, rowbias, ldrb, rows_per_sample, residual, ldr,
+                      alpha, flags, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int sdmi_gemm_ex(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
+                            int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
+                            int ldrb, int rows_per_sample, const void* residual, int ldr, float alpha, uint32_t flags, void* ws,
+                            int64_t ws_bytes, void* stream, const sdmi_epilogue_ext* ext) {
   SDMI_REQUIRE(a && w && out, "gemm: null pointer");
   SDMI_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0, "gemm: bad shape m=%d n=%d k=%d batch=%d", m, n, k, batch);
   SDMI_REQUIRE(k % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && lda >= k && ldw >= k, "gemm: k/lda/ldw must be multiples of 8 (k=%d lda=%d ldw=%d)", k, lda, ldw);
@@ -1038,19 +1276,58 @@ extern "C" int sdmi_gemm(const void* a, int lda, int64_t sa, const void* w, int 
   } else if (!(flags & SDMI_F_OUT_NCHW_F32)) {
     SDMI_REQUIRE(ldc % 4 == 0 && ldc >= n, "gemm: ldc must be a multiple of 4 and >= n (ldc=%d n=%d)", ldc, n);
   }
-  IgemmParams p = {};
-  p.a = (const u16*)a; p.w = (const u16*)w; p.out = out; p.bias = bias; p.rowbias = rowbias; p.res = (const u16*)residual;
-  p.sa = sa; p.sw = sw; p.sc = sc; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
-  p.M = m; p.N = n; p.K = k; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : m; p.alpha = alpha; p.flags = flags;
-  p.nk = (k + BK - 1) / BK;
-  p.kt_per_tap = 1;
-  return launch_igemm<false>(p, batch, ws, ws_bytes, (hipStream_t)stream);
+  IgemmParams p;
+  gemm_params(p, a, lda, sa, w, ldw, sw, out, ldc, sc, m, n, k, batch, bias, rowbias, ldrb, rows_per_sample, residual, ldr, alpha, flags);
+  return launch_igemm<false>(p, batch, ws, ws_bytes, (hipStream_t)stream, ext);
+}
+
+extern "C" int sdmi_gemm_stats_parts(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags, int* row_parts, int* col_parts) {
+  if (row_parts) *row_parts = 0;
+  if (col_parts) *col_parts = 0;
+  if (m <= 0 || n <= 0 || k <= 0 || batch <= 0) return SDMI_EINVAL;
+  IgemmParams p;
+  gemm_params(p, nullptr, k, 0, nullptr, k, 0, nullptr, n, 0, m, n, k, batch, nullptr, nullptr, 0, rows_per_sample, nullptr, 0, 1.0f, flags);
+  const int vi = plan_igemm<false>(p, batch, true, (int64_t)1 << 62);
+  stats_parts_of(p, batch, vi, row_parts, col_parts);
+  return SDMI_OK;
+}
+
+static void conv_params(IgemmParams& p, const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout,
+                        int hout, int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias, int ldrb,
+                        const void* residual, int ldr, void* out, int ldc, uint32_t flags) {
+  p = IgemmParams{};
+  p.a = (const u16*)x; p.w = (const u16*)w_packed; p.out = out; p.bias = bias; p.rowbias = rowbias; p.res = (const u16*)residual;
+  p.lda = ldx; p.ldw = 9 * cin; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
+  p.M = n * hout * wout; p.N = cout; p.K = 9 * cin; p.rows_per_sample = hout * wout; p.alpha = 1.0f; p.flags = flags;
+  p.H = h; p.W = w; p.Cin = cin; p.Ho = hout; p.Wo = wout; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.ups = (flags & SDMI_F_UPSAMPLE2X) ? 1 : 0;
+  p.kt_per_tap = (cin + BK - 1) / BK;
+  p.nk = 9 * p.kt_per_tap;
 }
 
 extern "C" int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout, int hout,
                             int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias, int ldrb,
                             const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* ws, int64_t ws_bytes,
                             void* stream) {
+  return sdmi_conv3x3_ex(x, ldx, n, h, w, cin, w_packed, cout, hout, wout, stride, pad_t, pad_l, bias, rowbias, ldrb, residual, ldr,
+                         out, ldc, flags, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int sdmi_conv3x3_stats_parts(int n, int h, int w, int cin, int cout, int hout, int wout, int stride, int pad_t, int pad_l,
+                                        uint32_t flags, int* row_parts) {
+  if (row_parts) *row_parts = 0;
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || hout <= 0 || wout <= 0) return SDMI_EINVAL;
+  IgemmParams p;
+  conv_params(p, nullptr, cin, n, h, w, cin, nullptr, cout, hout, wout, stride, pad_t, pad_l, nullptr, nullptr, 0, nullptr, 0, nullptr, cout, flags);
+  const int vi = plan_igemm<true>(p, 1, true, (int64_t)1 << 62);
+  stats_parts_of(p, 1, vi, row_parts, nullptr);
+  return SDMI_OK;
+}
+
+extern "C" int sdmi_conv3x3_ex(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout, int hout,
+                               int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias, int ldrb,
+                               const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* ws, int64_t ws_bytes,
+                               void* stream, const sdmi_epilogue_ext* ext) {
   SDMI_REQUIRE(x && w_packed && out, "conv3x3: null pointer");
   SDMI_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && hout > 0 && wout > 0, "conv3x3: bad shape");
   SDMI_REQUIRE(cin % 8 == 0 && ldx % 8 == 0 && ldx >= cin, "conv3x3: cin and ldx must be multiples of 8 (cin=%d ldx=%d)", cin, ldx);
@@ -1066,14 +1343,10 @@ extern "C" int sdmi_conv3x3(const void* x, int ldx, int n, int h, int w, int cin
   SDMI_REQUIRE(!(flags & (SDMI_F_GEGLU | SDMI_F_OUT_F32)), "conv3x3: unsupported flag");
   SDMI_REQUIRE(!(flags & SDMI_F_OUT_U8_IMAGE) || !(flags & SDMI_F_OUT_NCHW_F32), "conv3x3: two output layouts requested");
   if (!(flags & (SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE))) SDMI_REQUIRE(ldc % 4 == 0 && ldc >= cout, "conv3x3: ldc");
-  IgemmParams p = {};
-  p.a = (const u16*)x; p.w = (const u16*)w_packed; p.out = out; p.bias = bias; p.rowbias = rowbias; p.res = (const u16*)residual;
-  p.lda = ldx; p.ldw = 9 * cin; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
-  p.M = n * hout * wout; p.N = cout; p.K = 9 * cin; p.rows_per_sample = hout * wout; p.alpha = 1.0f; p.flags = flags;
-  p.H = h; p.W = w; p.Cin = cin; p.Ho = hout; p.Wo = wout; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.ups = ups;
-  p.kt_per_tap = (cin + BK - 1) / BK;
-  p.nk = 9 * p.kt_per_tap;
-  return launch_igemm<true>(p, 1, ws, ws_bytes, (hipStream_t)stream);
+  SDMI_REQUIRE(!(flags & SDMI_F_LNFOLD), "conv3x3: SDMI_F_LNFOLD is a gemm mode");
+  IgemmParams p;
+  conv_params(p, x, ldx, n, h, w, cin, w_packed, cout, hout, wout, stride, pad_t, pad_l, bias, rowbias, ldrb, residual, ldr, out, ldc, flags);
+  return launch_igemm<true>(p, 1, ws, ws_bytes, (hipStream_t)stream, ext);
 }
 
 extern "C" int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags) {

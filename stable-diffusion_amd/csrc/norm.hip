@@ -454,6 +454,142 @@ extern "C" int sdmi_groupnorm(const void* x, int ldx, void* y, int ldy, int n, i
   return sdmi_groupnorm_apply(x, ldx, scale_shift, y, ldy, n, hw, c, flags, stream);
 }
 
+// ------------------------------------------------------------------------------------ GroupNorm from producer statistics
+// The conv / GEMM that produced x already left per-channel (sum, sumsq) of its fp32 results per wave tile of rows
+// (sdmi_epilogue_ext.colstats, csrc/igemm.hip), so x is not read again for its statistics: one small kernel folds them
+// per (sample, group) into scale/shift (fp64, fixed order), then the apply pass runs.  Up to two channel segments: the
+// input of an up-path ResBlock is the concat of two producers' tensors (Unet.py:132), and a group may straddle them.
+struct GnSegs {
+  const float* stats[2];
+  int parts[2], ld[2], col0[2], c0[2], c[2];
+  int nseg;
+};
+constexpr int GNF_THREADS = 1024, GNF_WAVES = GNF_THREADS / 64, GNF_CHUNK = 4 * GNF_THREADS, GNF_MAX_CHUNKS = 64;
+// chunks: gridDim.z > 1 splits a (sample, group)'s partials over blocks (the 768x768 levels of the VAE have 18432 row parts);
+// each block then leaves its fp64 (sum, sumsq) in `chunk_out` and gn_finalize_chunks_kernel adds them in chunk order.
+__global__ __launch_bounds__(GNF_THREADS) void gn_finalize_cols_kernel(GnSegs sg, int groups, int c, int hw, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, float eps,
+                                                                       float* __restrict__ scale_shift, double* __restrict__ chunk_out) {
+  __shared__ double red[2][GNF_WAVES];
+  __shared__ float s_mr[2];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int cpg = c / groups;
+  const int maxparts = sg.nseg > 1 ? max(sg.parts[0], sg.parts[1]) : sg.parts[0];
+  const int total = cpg * maxparts;
+  const int per_z = ((total + gridDim.z - 1) / gridDim.z + GNF_CHUNK - 1) / GNF_CHUNK * GNF_CHUNK;
+  const int lo = blockIdx.z * per_z, hi = min(total, lo + per_z);
+  const float* const zp = (const float*)g_norm_zero16;
+  double s0 = 0.0, s1 = 0.0;
+  // four loads in flight per thread and iteration (a (sample, group) of 96x96x320 is 2880 partials: one iteration)
+  for (int base = lo; base < hi; base += GNF_CHUNK) {
+    float2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = base + j * GNF_THREADS + t;
+      const int part = idx / cpg, ch = g * cpg + (idx - part * cpg);
+      const int sgi = (sg.nseg > 1 && ch >= sg.c0[1]) ? 1 : 0;
+      const bool ok = idx < hi && part < sg.parts[sgi];
+      v[j] = *(const float2*)(ok ? sg.stats[sgi] + (((long long)n * sg.parts[sgi] + part) * sg.ld[sgi] + sg.col0[sgi] + (ch - sg.c0[sgi])) * 2 : zp);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s0 += (double)v[j].x; s1 += (double)v[j].y; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+  if (lane == 0) { red[0][wv] = s0; red[1][wv] = s1; }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < GNF_WAVES; ++w) { a += red[0][w]; b += red[1][w]; }
+    if (gridDim.z > 1) {
+      double* o = chunk_out + (((long long)n * groups + g) * gridDim.z + blockIdx.z) * 2;
+      o[0] = a;
+      o[1] = b;
+    }
+    const double cnt = (double)hw * (double)cpg;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mr[0] = (float)mean;
+    s_mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  if (gridDim.z > 1) return;
+  __syncthreads();
+  if (t < cpg) {
+    const int ci = g * cpg + t;
+    const float sc = gamma[ci] * s_mr[1];
+    *(float2*)(scale_shift + ((long long)n * c + ci) * 2) = make_float2(sc, beta[ci] - s_mr[0] * sc);
+  }
+}
+// second level of a chunked fold: block (group, sample) adds the chunks in order and writes its channels' scale/shift
+__global__ __launch_bounds__(256) void gn_finalize_chunks_kernel(const double* __restrict__ chunks, int nchunks, int groups, int c, int hw,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, float* __restrict__ scale_shift) {
+  const int t = threadIdx.x, g = blockIdx.x, n = blockIdx.y;
+  const int cpg = c / groups;
+  const double* in = chunks + ((long long)n * groups + g) * nchunks * 2;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nchunks; ++k) { a += in[2 * k]; b += in[2 * k + 1]; }   // every thread, same order: no exchange needed
+  const double cnt = (double)hw * (double)cpg;
+  const double mean = a / cnt;
+  double var = b / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float fm = (float)mean, fr = (float)(1.0 / sqrt(var + (double)eps));
+  if (t < cpg) {
+    const int ci = g * cpg + t;
+    const float sc = gamma[ci] * fr;
+    *(float2*)(scale_shift + ((long long)n * c + ci) * 2) = make_float2(sc, beta[ci] - fm * sc);
+  }
+}
+extern "C" int64_t sdmi_groupnorm_colstats_ss_bytes(int n, int c, int groups) {
+  // scale/shift table + room for the chunked fold of very long partial lists (fp64 pairs)
+  return ((int64_t)n * c * 2 * (int64_t)sizeof(float) + 15) / 16 * 16 + (int64_t)n * groups * GNF_MAX_CHUNKS * 2 * (int64_t)sizeof(double);
+}
+
+extern "C" int sdmi_groupnorm_from_colstats(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups,
+                                            const float* gamma, const float* beta, float eps, uint32_t flags, int nseg,
+                                            const float* const* seg_stats, const int* seg_parts, const int* seg_ld,
+                                            const int* seg_col0, const int* seg_c0, const int* seg_c, float* scale_shift,
+                                            void* stream) {
+  SDMI_REQUIRE(x && y && gamma && beta && scale_shift && seg_stats && seg_parts && seg_ld && seg_col0 && seg_c0 && seg_c,
+               "groupnorm_from_colstats: null pointer");
+  SDMI_REQUIRE(n > 0 && hw > 0 && c > 0 && groups > 0 && c % groups == 0 && n <= 65535, "groupnorm_from_colstats: bad shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  SDMI_REQUIRE(c / groups <= 256, "groupnorm_from_colstats: more than 256 channels per group");
+  SDMI_REQUIRE(nseg == 1 || nseg == 2, "groupnorm_from_colstats: 1 or 2 segments");
+  GnSegs sg = {};
+  sg.nseg = nseg;
+  int next = 0;
+  for (int i = 0; i < nseg; ++i) {
+    SDMI_REQUIRE(seg_stats[i] && ((uintptr_t)seg_stats[i] & 7) == 0 && seg_parts[i] > 0 && seg_c[i] > 0 && seg_col0[i] >= 0 &&
+                     seg_ld[i] >= seg_col0[i] + seg_c[i],
+                 "groupnorm_from_colstats: bad segment %d", i);
+    SDMI_REQUIRE(seg_c0[i] == next, "groupnorm_from_colstats: segments must tile the channels in order (segment %d starts at %d, expected %d)", i, seg_c0[i], next);
+    next += seg_c[i];
+    sg.stats[i] = seg_stats[i]; sg.parts[i] = seg_parts[i]; sg.ld[i] = seg_ld[i]; sg.col0[i] = seg_col0[i]; sg.c0[i] = seg_c0[i]; sg.c[i] = seg_c[i];
+  }
+  SDMI_REQUIRE(next == c, "groupnorm_from_colstats: segments cover %d of %d channels", next, c);
+  int maxparts = sg.parts[0];
+  if (nseg > 1 && sg.parts[1] > maxparts) maxparts = sg.parts[1];
+  const long long total = (long long)(c / groups) * maxparts;
+  SDMI_REQUIRE(total < (1ll << 31), "groupnorm_from_colstats: too many partials");
+  int nchunks = (int)((total + 4 * GNF_CHUNK - 1) / (4 * GNF_CHUNK));   // a block folds up to four iterations' worth alone
+  if (nchunks > GNF_MAX_CHUNKS) nchunks = GNF_MAX_CHUNKS;
+  if (nchunks < 1) nchunks = 1;
+  double* chunk_ws = (double*)((char*)scale_shift + ((int64_t)n * c * 2 * (int64_t)sizeof(float) + 15) / 16 * 16);
+  hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(groups, n, nchunks), dim3(GNF_THREADS), 0, (hipStream_t)stream, sg, groups, c, hw, gamma,
+                     beta, eps, scale_shift, chunk_ws);
+  int rc = sdmi_check_launch("groupnorm finalize (colstats)");
+  if (rc) return rc;
+  if (nchunks > 1) {
+    hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, n), dim3(256), 0, (hipStream_t)stream, chunk_ws, nchunks, groups, c, hw, gamma,
+                       beta, eps, scale_shift);
+    rc = sdmi_check_launch("groupnorm finalize (chunks)");
+    if (rc) return rc;
+  }
+  return sdmi_groupnorm_apply(x, ldx, scale_shift, y, ldy, n, hw, c, flags, stream);
+}
+
 // ------------------------------------------------------------------------------------ GroupNorm without allocations
 // sdmi_groupnorm for callers that cannot allocate (HIP graph capture, tight serving loops): the per-(sample, channel)
 // scale/shift table and the per-block partial sums, which sdmi_groupnorm takes as caller-allocated buffers, live in a

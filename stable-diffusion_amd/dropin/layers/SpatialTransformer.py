@@ -53,8 +53,11 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
-    def run(self, a):
+    def run(self, a, ln=None):
+        """ln: the LayerNorm module in front of this layer, folded into the GEMM when `a` carries row statistics."""
         w = self.proj.weight
+        if ln is not None:
+            return E.gemm_ln(a, ln, (w,), bias=self.proj.bias, geglu=True)
         return E.gemm(a, E.packed_linear((w,), geglu=True), w.shape[0], bias=self.proj.bias, geglu=True)
 
     def forward(self, x):
@@ -66,8 +69,8 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.Sequential(GEGLU(dim, int(dim * mult)), nn.Dropout(dropout), nn.Linear(int(dim * mult), dim_out or dim))
 
-    def run(self, a, residual=None):
-        g = self.net[0].run(a)
+    def run(self, a, residual=None, ln=None):
+        g = self.net[0].run(a, ln)
         lin = self.net[2]
         return E.gemm(g, E.packed_linear((lin.weight,)), lin.weight.shape[0], bias=lin.bias, residual=residual)
 
@@ -100,16 +103,21 @@ class MemoryEfficientCrossAttention(nn.Module):
         self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
         self.attention_op = None
 
-    def run(self, a, context=None, residual=None):
+    def run(self, a, context=None, residual=None, ln=None, rowstats=False):
+        """ln: the LayerNorm module in front of this layer (BasicTransformerBlock.norm1/2): `a` is then the UN-normalised
+        token stream and the LayerNorm is folded into the q (|k|v) projection.  rowstats: leave per-row statistics of the
+        result for the LayerNorm that follows."""
         inner = 64 * self.heads
+        proj = (lambda ws: E.gemm_ln(a, ln, ws)) if ln is not None else \
+               (lambda ws: E.gemm(a, E.packed_linear(ws), sum(w.shape[0] for w in ws)))
         if context is None:          # self-attention: one fused q|k|v GEMM
             if self.to_k.weight.shape[1] != a.c:
                 raise E.L.SdmiError("attention without context: to_k expects %d channels, the tokens have %d (the reference "
                                     "fails in to_k as well)" % (self.to_k.weight.shape[1], a.c))
-            qkv = E.gemm(a, E.packed_linear((self.to_q.weight, self.to_k.weight, self.to_v.weight)), 3 * inner)
+            qkv = proj((self.to_q.weight, self.to_k.weight, self.to_v.weight))
             q, k, v = qkv.cols(0, inner), qkv.cols(inner, inner), qkv.cols(2 * inner, inner)
         else:
-            q = E.gemm(a, E.packed_linear((self.to_q.weight,)), inner)
+            q = proj((self.to_q.weight,))
             if isinstance(context, ContextKV):
                 kv = context.kv[id(self)]
             else:
@@ -117,7 +125,7 @@ class MemoryEfficientCrossAttention(nn.Module):
             k, v = kv.cols(0, inner), kv.cols(inner, inner)
         o = E.attention(q, k, v, self.heads)
         lin = self.to_out[0]
-        return E.gemm(o, E.packed_linear((lin.weight,)), lin.weight.shape[0], bias=lin.bias, residual=residual)
+        return E.gemm(o, E.packed_linear((lin.weight,)), lin.weight.shape[0], bias=lin.bias, residual=residual, rowstats=rowstats)
 
     def forward(self, x, context=None, mask=None):
         if mask is not None:
@@ -160,19 +168,25 @@ class BasicTransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.norm3 = nn.LayerNorm(dim)
 
+    # Each LayerNorm is folded into the GEMM that consumes it (E.gemm_ln): the GEMM that produced the token stream left
+    # per-row (sum, sumsq), the consumer multiplies the un-normalised rows by gamma-scaled weights and corrects per row in
+    # its epilogue.  No LayerNorm launch, no normalised copy of the stream.
     def run_attn1(self, t):
         """The context-free head of the block: x + attn1(LN(x))."""
-        return self.attn1.run(E.layernorm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps), None, residual=t)
+        return self.attn1.run(t, None, residual=t, ln=self.norm1, rowstats=True)
 
     def run(self, t, context=None, taps=None, after_attn1=False):
         if not after_attn1:
             t = self.run_attn1(t)
         if taps is not None:
             taps["attn1"] = t
-        t = self.attn2.run(E.layernorm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps), context, residual=t)
+        if context is None:     # cross-attention degenerates to self-attention over LN(x) (reference :70-72)
+            t = self.attn2.run(E.layernorm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps), None, residual=t, rowstats=True)
+        else:
+            t = self.attn2.run(t, context, residual=t, ln=self.norm2, rowstats=True)
         if taps is not None:
             taps["attn2"] = t
-        t = self.ff.run(E.layernorm(t, self.norm3.weight, self.norm3.bias, self.norm3.eps), residual=t)
+        t = self.ff.run(t, residual=t, ln=self.norm3)
         if taps is not None:
             taps["ff"] = t
         return t
@@ -196,18 +210,18 @@ class SpatialTransformer(nn.Module):
         stream that `run(a, context, prefix=...)` continues from.  Depends on `a` only, so the two halves of a CFG batch
         (same latent, same timestep, different prompt) can share it."""
         xn = E.groupnorm(a, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
-        t = E.gemm(xn, E.packed_linear((self.proj_in.weight,)), self.proj_in.weight.shape[0], bias=self.proj_in.bias)
+        t = E.gemm(xn, E.packed_linear((self.proj_in.weight,)), self.proj_in.weight.shape[0], bias=self.proj_in.bias, rowstats=True)
         return self.transformer_blocks[0].run_attn1(t)
 
     def run(self, a, context=None, out=None, taps=None, prefix=None):
         if prefix is None:
             xn = E.groupnorm(a, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
-            t = E.gemm(xn, E.packed_linear((self.proj_in.weight,)), self.proj_in.weight.shape[0], bias=self.proj_in.bias)
+            t = E.gemm(xn, E.packed_linear((self.proj_in.weight,)), self.proj_in.weight.shape[0], bias=self.proj_in.bias, rowstats=True)
             t = self.transformer_blocks[0].run(t, context, taps)
         else:
             t = self.transformer_blocks[0].run(prefix, context, taps, after_attn1=True)
         return E.gemm(t, E.packed_linear((self.proj_out.weight,)), self.proj_out.weight.shape[0], bias=self.proj_out.bias,
-                      residual=a, out=out)
+                      residual=a, out=out, colstats=True)
 
     def forward(self, x, t_emb=None, context=None):
         if isinstance(context, list):

@@ -3,7 +3,9 @@
 PyTorch is used for device memory (torch.empty), the current HIP stream and parameter storage only; all
 arithmetic runs in libsdmi355.so.  There is no fallback: a missing library raises (see _lib.load).
 """
+import ctypes
 import math
+import os
 import weakref
 
 import torch
@@ -33,11 +35,17 @@ def _need_cuda(t, what):
 
 
 class Act(object):
-    """(n, h, w, c) activation stored NHWC bf16: buf[n, h*w, ld_total], columns [off, off+c)."""
-    __slots__ = ("buf", "n", "h", "w", "c", "off")
+    """(n, h, w, c) activation stored NHWC bf16: buf[n, h*w, ld_total], columns [off, off+c).
 
-    def __init__(self, buf, n, h, w, c, off=0):
+    stats: {column offset: (colstats tensor, row parts per sample, channels)} left by the kernels that produced column
+    ranges of the buffer (shared by every view of it): per-channel sums for the GroupNorm that follows.
+    rstats: (rowstats tensor, column parts) left by the GEMM that produced this view: per-row sums for a LayerNorm."""
+    __slots__ = ("buf", "n", "h", "w", "c", "off", "stats", "rstats")
+
+    def __init__(self, buf, n, h, w, c, off=0, stats=None):
         self.buf, self.n, self.h, self.w, self.c, self.off = buf, n, h, w, c, off
+        self.stats = {} if stats is None else stats
+        self.rstats = None
 
     @property
     def hw(self):
@@ -56,7 +64,7 @@ class Act(object):
         return self.buf.device
 
     def cols(self, off, c):
-        return Act(self.buf, self.n, self.h, self.w, c, self.off + off)
+        return Act(self.buf, self.n, self.h, self.w, c, self.off + off, self.stats)
 
 
 def new_act(n, h, w, c, device):
@@ -188,9 +196,51 @@ def _check_out(res, n, h, w, c, what):
 
 
 # --------------------------------------------------------------------------- ops
+USE_COLSTATS = os.environ.get("SDMI_COLSTATS", "1") == "1"     # GroupNorm statistics from the producer's epilogue (A/B switch)
+USE_LNFOLD = os.environ.get("SDMI_LNFOLD", "1") == "1"         # LayerNorm folded into the GEMM that follows it (A/B switch)
+
+
+def _gn_small(hw, c, groups):
+    """sdmi_groupnorm's rule for its fused single-launch kernel (csrc/norm.hip): such tensors gain nothing from colstats."""
+    cpg = c // groups
+    dwords = hw * (cpg // 2)
+    return dwords <= 12 * 1024 or (dwords <= 24 * 1024 and cpg >= 40)
+
+
+def _stat_segments(a):
+    """The colstats entries that tile columns [a.off, a.off + a.c) of a's buffer exactly, in order; None if they do not."""
+    segs, pos = [], a.off
+    while pos < a.off + a.c:
+        e = a.stats.get(pos)
+        if e is None or len(segs) == 2:
+            return None
+        segs.append(e)
+        pos += e[2]
+    return segs if pos == a.off + a.c else None
+
+
 def groupnorm(a, weight, bias, eps, silu, groups=32):
-    """GroupNorm(+SiLU): one fused launch when a (sample, group) slice fits a block, else stats + apply (csrc/norm.hip)."""
+    """GroupNorm(+SiLU): one fused launch when a (sample, group) slice fits a block; else, when the kernels that produced
+    `a` left per-channel statistics (colstats), a fold of those + apply; else stats + apply (csrc/norm.hip)."""
     dev = a.device
+    segs = _stat_segments(a) if (USE_COLSTATS and not _gn_small(a.hw, a.c, groups)) else None
+    if segs is not None:
+        import ctypes as C
+        ns = len(segs)
+        ss = torch.empty((L.load().sdmi_groupnorm_colstats_ss_bytes(a.n, a.c, groups) // 4,), dtype=torch.float32, device=dev)
+        y = new_act(a.n, a.h, a.w, a.c, dev)
+        ptrs = (C.c_void_p * 2)(*[t.data_ptr() for t, _, _ in segs] + [0] * (2 - ns))
+        ivec = lambda v: (C.c_int * 2)(*(list(v) + [0] * (2 - ns)))
+        c0, acc = [], 0
+        for _, _, cc in segs:
+            c0.append(acc)
+            acc += cc
+        L.call("sdmi_groupnorm_from_colstats", a.ptr, a.ld, y.ptr, y.ld, a.n, a.hw, a.c, groups,
+               _f32c(weight, "gn weight").data_ptr(), _f32c(bias, "gn bias").data_ptr(), float(eps), L.F_SILU if silu else 0, ns,
+               C.cast(ptrs, C.c_void_p), C.cast(ivec(p for _, p, _ in segs), C.c_void_p), C.cast(ivec(cc for _, _, cc in segs), C.c_void_p),
+               C.cast(ivec([0] * ns), C.c_void_p), C.cast(ivec(c0), C.c_void_p), C.cast(ivec(cc for _, _, cc in segs), C.c_void_p),
+               ss.data_ptr(), _stream())
+        return y
     ss = torch.empty((a.n, a.c, 2), dtype=torch.float32, device=dev)
     ws = torch.empty((L.load().sdmi_groupnorm_ws_bytes(a.n, a.hw, a.c) // 4,), dtype=torch.float32, device=dev)
     y = new_act(a.n, a.h, a.w, a.c, dev)
@@ -250,13 +300,28 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
         _check_out(res, a.n, ho, wo, cout, "conv3x3")
         optr, ldc = res.ptr, res.ld
     ws, wsb = _workspace(a.device, L.load().sdmi_conv3x3_ws_bytes(a.n, cin, cout, ho, wo))
-    L.call("sdmi_conv3x3", a.ptr, a.ld, a.n, a.h, a.w, cin, wp.data_ptr(), cout, ho, wo, stride, pt, pl,
-           _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags, ws, wsb, _stream())
+    ext = None
+    if USE_COLSTATS and isinstance(res, Act) and ho * wo >= 2304:
+        # leave per-channel statistics for the GroupNorm that follows (large tensors only: small ones use the fused kernel)
+        rp = ctypes.c_int(0)
+        L.call("sdmi_conv3x3_stats_parts", a.n, a.h, a.w, cin, cout, ho, wo, stride, pt, pl, flags, ctypes.addressof(rp))
+        if rp.value > 0:
+            cs = torch.empty((rp.value, cout, 2), dtype=torch.float32, device=a.device)
+            ext = L.EpilogueExt(colstats=cs.data_ptr())
+            res.stats[res.off] = (cs, rp.value // a.n, cout)
+    if ext is None and isinstance(res, Act):
+        res.stats.pop(res.off, None)
+    L.call("sdmi_conv3x3_ex", a.ptr, a.ld, a.n, a.h, a.w, cin, wp.data_ptr(), cout, ho, wo, stride, pt, pl,
+           _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags, ws, wsb, _stream(),
+           ctypes.addressof(ext) if ext is not None else 0)
     return res
 
 
-def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shape=None):
-    """Token GEMM: rows = n*hw of `a`, W packed [n_out][a.c]. Returns an Act with c = n_out (or n_out/2 for GEGLU)."""
+def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shape=None, colstats=False, rowstats=False, ln=None):
+    """Token GEMM: rows = n*hw of `a`, W packed [n_out][a.c]. Returns an Act with c = n_out (or n_out/2 for GEGLU).
+    colstats / rowstats: also leave per-channel / per-row statistics for a GroupNorm / LayerNorm that follows (where the
+    problem can: res.stats / res.rstats tell).  ln = (u, eps): LayerNorm folded in (wp and bias from packed_linear_ln;
+    `a` must carry rstats)."""
     m = a.n * a.hw
     cres = n_out // 2 if geglu else n_out
     res = out if out is not None else new_act(a.n, a.h, a.w, cres, a.device)
@@ -271,10 +336,75 @@ def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shap
     if residual is not None:
         flags |= L.F_RESIDUAL
         res_ptr, ldr = residual.ptr, residual.ld
+    ext = None
+    if ln is not None:
+        u, eps = ln
+        rst, parts = a.rstats
+        flags |= L.F_LNFOLD
+        ext = L.EpilogueExt(ln_rowstats=rst.data_ptr(), ln_u=u.data_ptr(), ln_parts=parts, ln_eps=float(eps))
+    res.rstats = None
+    keep_cs = False
+    if (colstats and USE_COLSTATS and a.hw >= 2304) or rowstats:
+        rp, cp = ctypes.c_int(0), ctypes.c_int(0)
+        L.call("sdmi_gemm_stats_parts", m, n_out, a.c, 1, a.hw, flags, ctypes.addressof(rp), ctypes.addressof(cp))
+        if colstats and USE_COLSTATS and a.hw >= 2304 and rp.value > 0:
+            cs = torch.empty((rp.value, n_out, 2), dtype=torch.float32, device=a.device)
+            ext = ext or L.EpilogueExt()
+            ext.colstats = cs.data_ptr()
+            res.stats[res.off] = (cs, rp.value // a.n, n_out)
+            keep_cs = True
+        if rowstats and cp.value > 0:
+            rs = torch.empty((m, cp.value, 2), dtype=torch.float32, device=a.device)
+            ext = ext or L.EpilogueExt()
+            ext.rowstats = rs.data_ptr()
+            res.rstats = (rs, cp.value)
+    if not keep_cs:
+        res.stats.pop(res.off, None)
     ws, wsb = _workspace(a.device, L.load().sdmi_gemm_ws_bytes(m, n_out, a.c, 1, a.hw, flags))
-    L.call("sdmi_gemm", a.ptr, a.ld, 0, wp.data_ptr(), wp.shape[1], 0, res.ptr, res.ld, 0, m, n_out, a.c, 1,
-           _ptr(bias), 0, 0, a.hw, res_ptr, ldr, 1.0, flags, ws, wsb, _stream())
+    L.call("sdmi_gemm_ex", a.ptr, a.ld, 0, wp.data_ptr(), wp.shape[1], 0, res.ptr, res.ld, 0, m, n_out, a.c, 1,
+           _ptr(bias), 0, 0, a.hw, res_ptr, ldr, 1.0, flags, ws, wsb, _stream(),
+           ctypes.addressof(ext) if ext is not None else 0)
     return res
+
+
+def packed_linear_ln(weights, ln_weight, ln_bias, bias=None, geglu=False):
+    """Weights of the Linear(s) that follow a LayerNorm, with the LayerNorm folded in (sdmi_pack_linear_ln): returns
+    (packed h16 [sum N_i][K] with gamma folded, u fp32 [sum N_i] in packed row order, v fp32 [sum N_i] = beta.W + bias)."""
+    weights = tuple(weights)
+    biases = tuple(bias) if isinstance(bias, (tuple, list)) else ((bias,) if bias is not None else ())
+    if geglu and len(weights) != 1:
+        raise L.SdmiError("packed_linear_ln: GEGLU packs one weight")
+
+    def build():
+        k = weights[0].shape[1]
+        ntot = sum(w.shape[0] for w in weights)
+        dev = weights[0].device
+        wp = torch.empty((ntot, k), dtype=act_dtype(), device=dev)
+        u = torch.empty((ntot,), dtype=torch.float32, device=dev)
+        v = torch.empty((ntot,), dtype=torch.float32, device=dev)
+        g, b = _f32c(ln_weight, "ln weight"), _f32c(ln_bias, "ln bias")
+        r = 0
+        for i, w in enumerate(weights):
+            w = _f32c(w, "linear weight")
+            bi = _f32c(biases[i], "linear bias").data_ptr() if biases else 0
+            L.call("sdmi_pack_linear_ln", w.data_ptr(), g.data_ptr(), b.data_ptr(), bi, wp.data_ptr() + 2 * r * k,
+                   u.data_ptr() + 4 * r, v.data_ptr() + 4 * r, w.shape[0], k, 1 if geglu else 0, _stream())
+            r += w.shape[0]
+        return wp, u, v
+    return PACK.get(weights + (ln_weight, ln_bias) + biases, "lnl" + ("g" if geglu else ""), build)
+
+
+def gemm_ln(a, ln_mod, weights, bias=None, geglu=False, **kw):
+    """LayerNorm(a) @ W^T (+bias): folded into one GEMM when `a` carries row statistics from its producer (gemm(...,
+    rowstats=True)), else the LayerNorm kernel followed by the plain GEMM."""
+    weights = tuple(weights)
+    n_out = sum(w.shape[0] for w in weights)
+    if USE_LNFOLD and a.rstats is not None:
+        wp, u, v = packed_linear_ln(weights, ln_mod.weight, ln_mod.bias, bias, geglu)
+        return gemm(a, wp, n_out, bias=v, geglu=geglu, ln=(u, ln_mod.eps), **kw)
+    x = layernorm(a, ln_mod.weight, ln_mod.bias, ln_mod.eps)
+    b = stacked_f32(tuple(bias)) if isinstance(bias, (tuple, list)) else bias
+    return gemm(x, packed_linear(weights, geglu=geglu), n_out, bias=b, geglu=geglu, **kw)
 
 
 def attention(q, k, v, heads, out=None):

@@ -185,3 +185,117 @@ def test_two_process_sharded_sampler_equals_unsharded():
     ok = q.get(timeout=110)
     [p.join(timeout=60) for p in procs]
     assert ok and all(p.exitcode == 0 for p in procs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# normalisation fused into the neighbouring kernels: statistics from the producer's epilogue, LayerNorm folded into the
+# consumer GEMM (reference layers/ResBlock.py:65-74, layers/SpatialTransformer.py:182-184, :212)
+def _h16(x):
+    return x.to(E.act_dtype()).float()
+
+
+def _gate(got, ref, max_tol, l2_tol, what):
+    m, l2 = rel_err(got.float().cpu().numpy(), ref.numpy())
+    print("%s: max-rel %.3e rel-L2 %.3e" % (what, m, l2))
+    assert m <= max_tol * _tol() and l2 <= l2_tol * _tol(), (what, m, l2)
+
+
+@pytest.mark.parametrize("m,n,k", [(2304, 320, 320), (4608, 640, 1280), (2304, 1280, 640), (256, 128, 128)])
+def test_gemm_row_and_col_statistics(m, n, k):
+    """sdmi_gemm_ex statistics outputs against fp64 sums of the fp32 result (bias + residual included)."""
+    rs = np.random.RandomState(m + n)
+    a, w = _h16(T(rs.randn(m, k).astype(np.float32))), _h16(T((rs.randn(n, k) / np.sqrt(k)).astype(np.float32)))
+    b, r = T(rs.randn(n).astype(np.float32)), _h16(T(rs.randn(m, n).astype(np.float32)))
+    ref = (a.double() @ w.double().t() + b.double() + r.double())
+    A = E.Act(a.to(E.act_dtype()).to(DEV).reshape(1, m, k), 1, 1, m, k)
+    R = E.Act(r.to(E.act_dtype()).to(DEV).reshape(1, m, n), 1, 1, m, n)
+    saved = E.USE_COLSTATS
+    E.USE_COLSTATS = True
+    try:
+        out = E.gemm(A, w.to(E.act_dtype()).to(DEV).contiguous(), n, bias=b.to(DEV), residual=R, colstats=True, rowstats=True)
+    finally:
+        E.USE_COLSTATS = saved
+    _gate(out.buf.reshape(m, n), ref.float(), 1.5e-3, 6e-4, "gemm %dx%dx%d" % (m, n, k))
+    assert out.rstats is not None
+    rst, parts = out.rstats
+    got = rst.double().sum(dim=1).cpu()                                   # (m, 2)
+    want = torch.stack([ref.sum(dim=1), (ref * ref).sum(dim=1)], dim=1)
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-5
+    if m >= 2304:
+        cs, pps, cc = out.stats[0]
+        assert cc == n and cs.shape[0] == pps
+        got = cs.double().sum(dim=0).cpu()                                # (n, 2)
+        want = torch.stack([ref.sum(dim=0), (ref * ref).sum(dim=0)], dim=1)
+        assert float((got - want).abs().max() / want.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("m,c,nout,geglu", [(2304, 320, 960, False), (9216, 320, 320, False), (1152, 640, 5120, True),
+                                            (576, 1280, 3840, False), (144, 1280, 10240, True), (200, 128, 384, False)])
+def test_layernorm_folded_into_gemm(m, c, nout, geglu):
+    """x -> [GEMM with rowstats] -> t;  LayerNorm(t) @ W^T (+bias) as ONE GEMM (LNFOLD) against the fp32 definition."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(m + nout)
+    x = _h16(T(rs.randn(m, c).astype(np.float32)))
+    w0 = _h16(T((rs.randn(c, c) / np.sqrt(c)).astype(np.float32)))
+    b0 = T((rs.randn(c) * 0.7 + 0.4).astype(np.float32))                 # rows with a mean well away from zero
+    ln = torch.nn.LayerNorm(c)
+    ln.weight.data = T((1.0 + 0.3 * rs.randn(c)).astype(np.float32))
+    ln.bias.data = T((0.2 * rs.randn(c)).astype(np.float32))
+    w1 = T((rs.randn(nout, c) / np.sqrt(c)).astype(np.float32))
+    b1 = T(rs.randn(nout).astype(np.float32))
+    ln = ln.to(DEV)
+    W1, B1 = torch.nn.Parameter(w1.to(DEV)), torch.nn.Parameter(b1.to(DEV))
+    A = E.Act(x.to(E.act_dtype()).to(DEV).reshape(1, m, c), 1, 1, m, c)
+    t = E.gemm(A, w0.to(E.act_dtype()).to(DEV).contiguous(), c, bias=b0.to(DEV), rowstats=True)
+    assert t.rstats is not None
+    saved = E.USE_LNFOLD
+    E.USE_LNFOLD = True
+    try:
+        out = E.gemm_ln(t, ln, (W1,), bias=B1, geglu=geglu)
+    finally:
+        E.USE_LNFOLD = saved
+    tf = t.buf.reshape(m, c).float().cpu()                                # what the second GEMM reads
+    with torch.no_grad():
+        h = F.layer_norm(tf, (c,), ln.weight.detach().cpu(), ln.bias.detach().cpu(), ln.eps) @ w1.t() + b1
+    if geglu:
+        xx, g = h.chunk(2, dim=-1)
+        h = xx * F.gelu(g)
+    _gate(out.buf.reshape(m, -1), h, 3e-3, 1.2e-3, "LN-folded gemm m=%d c=%d n=%d%s" % (m, c, nout, " geglu" if geglu else ""))
+    # and against the unfused path (LayerNorm kernel + plain GEMM): same thing within the same budget
+    E.USE_LNFOLD = False
+    try:
+        out2 = E.gemm_ln(t, ln, (W1,), bias=B1, geglu=geglu)
+    finally:
+        E.USE_LNFOLD = saved
+    _gate(out2.buf.reshape(m, -1), h, 3e-3, 1.2e-3, "  unfused")
+
+
+@pytest.mark.parametrize("hh,cin,cout", [(96, 320, 320), (96, 640, 320), (48, 640, 640)])
+def test_resblock_large_vs_oracle_with_colstats(hh, cin, cout):
+    """ResBlock at the sizes where GroupNorm takes its statistics from the producing conv's epilogue (>= 48x48): against
+    the fp32 oracle, and the statistics path against the re-reading path."""
+    from layers.ResBlock import ResBlock
+    rs = np.random.RandomState(hh + cin)
+    m = ResBlock(cin, cout, 1280)
+    sd = {k: v.clone() for k, v in fill_state_dict(m.state_dict(), seed=21).items()}
+    m = m.to(DEV).eval()
+    x = T(rs.randn(1, cin, hh, hh).astype(np.float32))
+    temb = T(rs.randn(1, 1280).astype(np.float32))
+    with torch.no_grad():
+        ref = O.resblock({"b." + k: v for k, v in sd.items()}, "b", x, temb)
+    saved = E.USE_COLSTATS
+    outs = {}
+    for mode in (True, False):
+        E.USE_COLSTATS = mode
+        try:
+            # norm2 reads the statistics conv1's epilogue left; conv2 leaves its own for the next block
+            a = E.from_nchw(x.to(DEV))
+            emb = E.linear_small_m(temb.to(DEV), E.packed_linear((m.emb_proj.weight,)), m.emb_proj.bias, silu_in=True)
+            y = m.run(a, emb, emb.shape[1])
+            outs[mode] = E.to_nchw(y)
+            if mode and hh >= 96:       # (at 48x48 and batch 1 the convs run split-K: no statistics, the re-reading path)
+                assert y.stats, "conv2 left no statistics"
+        finally:
+            E.USE_COLSTATS = saved
+    _gate(outs[True], ref, 4e-3, 1.5e-3, "ResBlock %dx%d %d->%d (colstats)" % (hh, hh, cin, cout))
+    _gate(outs[False], ref, 4e-3, 1.5e-3, "  re-reading path")
