@@ -47,7 +47,7 @@ def work_of(name, a):
     if name.startswith("igemm_kernel"):
         m, n, k, b = a[9], a[10], a[11], a[12]
         return 2.0 * m * n * k * b, 2.0 * b * (m * k + n * k + m * n)
-    if name == "attn64_kernel":
+    if name.startswith("attn64"):
         b, h, nq, nk = a[12], a[13], a[14], a[15]
         return 4.0 * b * h * nq * nk * 64, 2.0 * b * h * 64 * (2 * nq + 2 * nk)
     if name == "sdmi_groupnorm":

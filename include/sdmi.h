@@ -208,6 +208,12 @@ int sdmi_timestep_embedding(const int64_t* t, const float* freqs, float* out, in
 int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
                    int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv,
                    float scale, void* stream);
+/*      Same, for q that already carries scale * log2(e): o = softmax_base2(q k^T) v.  The caller folds the factor into the
+ *      query projection's weights before they are rounded to 16 bits (to_q at layers/SpatialTransformer.py:60,78), so the
+ *      kernel exponentiates the MFMA result as it stands and q sees no second rounding. */
+int sdmi_attention_log2q(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
+                         int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv,
+                         void* stream);
 
 /* ---- row softmax (VAE single-head d=512 attention, layers/SpatialTransformer.py:151, runs as
  *      score GEMM -> this -> value GEMM).  x fp32 [rows][ldx] -> y bf16 [rows][ldy], y = softmax(x*scale). */

@@ -38,7 +38,7 @@ for name, work, e0, e1 in kt.records:
     elif kname.startswith("igemm_kernel"):
         m, n, k, b = a[9], a[10], a[11], a[12]
         key = ("gemm" + ("-geglu" if a[20] & 8 else ""), m, n, k); fl = 2.0 * m * n * k * b
-    elif kname == "attn64_kernel":
+    elif kname.startswith("attn64"):
         b, h, nq, nk = a[12], a[13], a[14], a[15]
         key = ("attn", nq, nk, h); fl = 4.0 * b * h * nq * nk * 64
     elif kname == "igemm_splitk_reduce_kernel":

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
     "sdmi_timestep_embedding": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),
+    "sdmi_attention_log2q": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "sdmi_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "sdmi_cfg_ddim_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
@@ -144,8 +145,8 @@ def call(name, *args):
                 TIMER.records.append((name, TIMER.work_fn(name, args), e0, mid))
                 TIMER.records.append((kern[1], (0.0, 0.0), mid, e1))
                 e0 = None
-        elif name == "sdmi_attention":
-            name = "attn64_kernel"
+        elif name in ("sdmi_attention", "sdmi_attention_log2q"):
+            name = lib.sdmi_last_kernel().decode() or "attn64_kernel"
         if e0 is not None:
             TIMER.records.append((name, TIMER.work_fn(name, args), e0, e1))
     else:

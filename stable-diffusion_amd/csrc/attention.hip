@@ -210,9 +210,290 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
   }
 }
 
-extern "C" int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
-                              int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv,
-                              float scale, void* stream) {
+// ------------------------------------------------------------------------------------------ 64 query rows per wave
+// Second structure, for long self-attention (the 96x96 / 128x128 levels: 9216 / 16384 tokens).  The SQ counters of the
+// kernel above (profiles/r02_attn_pmc.txt) show it VALU-issue bound: per 32 x 64 wave-tile 16 MFMAs (512 matrix-pipe cycles)
+// against ~150 vector instructions at 4 - 8 issue cycles each, a third of the time neither pipe busy (dependency chain
+// QK^T -> row max -> cross-half exchange through the LDS -> exp -> PV, once per tile and wave).  Here
+//   * a wave owns 64 rows = two independent 32-row chains (half the K / V fragment reads per row);
+//   * a block is 128 rows x 2 halves of the key range: waves 0/1 sweep the first half of the keys for rows 0-63 / 64-127,
+//     waves 2/3 the second half, each pair with its own double-buffered K/V stream; the halves' (m, l, O) are merged
+//     through the LDS at the end.  Work then comes in units of 64 rows x half the keys: 9216 tokens x 10 (batch, head)
+//     pairs give 2880 units for 1024 SIMDs (94 % after rounding up to whole units, against 70 % for 64 rows x all keys);
+//   * Q is pre-scaled by scale * log2(e) and the running maximum enters the scores as the initial accumulator, so exp2()
+//     applies to the MFMA result as it stands;
+//   * the maximum is only raised when a row's scores exceed it by more than 2^8 (checked per 32-key block on each lane's
+//     own half of the keys, wave-uniform branch; the cross-half exchange happens only inside that rare branch): p <= 256
+//     keeps fp16's relative precision, and the exps no longer wait for a max reduction.
+constexpr float ATTN_DEFER_LOG2 = 8.0f;  // raise the running maximum only when a block's scores exceed it by more than this
+
+// One 32-key block (half kb of the staged 64-key tile) for one wave: two 32-row chains.
+template <bool FIRST, bool TAIL>
+__device__ __forceinline__ void attn2_block(const u16* sK, const u16* sV, int kb, const hx8 (&qf)[2][4], f32x16 (&oacc)[2][2],
+                                            f32x16 (&negm)[2], float (&mrun)[2], float (&lrun)[2], int key0, int nkv, int r, int hh,
+                                            int dblk, int tq, int tp) {
+  hx8 kf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const hx8*)&sK[k_off(32 * kb + r, 2 * ks + hh)];
+  f32x16 s[2];
+  // = q.k * scale * log2(e) - m: the first MFMA of a chain reads -m as C and writes another register tile (the builtin
+  // ties C to D and copies the 16 registers first: 32 moves per block for the two chains)
+  asm(MFMA32_MNEMONIC " %0, %2, %3, %5\n\t" MFMA32_MNEMONIC " %1, %2, %4, %6"
+      : "=&v"(s[0]), "=&v"(s[1])
+      : "v"(kf[0]), "v"(qf[0][0]), "v"(qf[1][0]), "v"(negm[0]), "v"(negm[1]));
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) s[qb] = MFMA32(kf[ks], qf[qb][ks], s[qb], 0, 0, 0);
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (key >= nkv) { s[0][i] = -1e30f; s[1][i] = -1e30f; }
+    }
+  }
+  float mx[2];  // maximum over this lane's 16 keys of the block (the other 16 sit on lane ^ 32)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float m0 = s[qb][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m0 = fmaxf(m0, s[qb][i]);
+    mx[qb] = m0;
+  }
+  const bool raise = FIRST || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > ATTN_DEFER_LOG2) != 0;
+  if (raise) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float mrow = fmaxf(mx[qb], __shfl_xor(mx[qb], 32));
+      // FIRST: the maximum starts at 0 (a zero C tile); move it to the block's maximum, whatever its sign; O and l are zero
+      const float delta = FIRST ? mrow : fmaxf(mrow, 0.f);
+      mrun[qb] += delta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[qb][i] -= delta;
+      if constexpr (!FIRST) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        lrun[qb] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[qb][0][i] *= alpha; oacc[qb][1][i] *= alpha; }
+      }
+      // -(m + delta), element by element from the old tile (a fresh splat is a new value to the register allocator, which
+      // then keeps two copies of the tile and moves 32 registers per block on the common path)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[qb][i] -= delta;
+    }
+  }
+  // exp -> fp16 P -> PV in two 16-key halves: the second half's exps issue behind the first half's MFMAs
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    hx8 pb[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[qb][j] = (h16)__builtin_amdgcn_exp2f(s[qb][8 * s2 + j]);
+      // row sums of the rounded P (what the PV product sees), two elements per instruction
+      union { hx8 v; hx2 h[4]; } u;
+      u.v = pb[qb];
+      const hx2 ones = {(h16)1.0f, (h16)1.0f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lrun[qb] = DOT2H(u.h[j], ones, lrun[qb]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int c = 4 * dt + 2 * dblk + (tp >> 1);
+      const int row0 = 32 * kb + 16 * s2 + 4 * hh + tq;
+      const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0, c) + 4 * (tp & 1)));
+      const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (short4_t __attribute__((address_space(3)))*)(sV + v_off(row0 + 8, c) + 4 * (tp & 1)));
+      union { struct { short4_t a, b; } h; hx8 v; } u;
+      u.h.a = lo;
+      u.h.b = hi;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) oacc[qb][dt] = MFMA32(u.v, pb[qb], oacc[qb][dt], 0, 0, 0);
+    }
+  }
+}
+
+// K/V staging of this kernel is LDS-DMA issued from inline asm (M0 = LDS base of the wave's 1 KB piece, then
+// global_load_lds_dwordx4): the compiler does not see an LDS write, so fragment reads through run-time selected buffer
+// pointers are not held back behind "vmcnt(0)" for a DMA they cannot alias (with the builtin that needs separately
+// named arrays and one copy of the loop per buffer order; two streams would need four copies).  The waits are explicit:
+// s_waitcnt vmcnt(0) in front of the barrier that ends a tile.  No compiler-generated code in this kernel uses M0.
+__device__ __forceinline__ void attn2_dma16(const void* src, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
+}
+
+__global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnParams p) {
+  // tile images [stream][buffer][K | V]; afterwards the second stream's O passes through its images to the first stream
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * 2 * 2 * 4096];
+  __shared__ float sML[2][4 * 64];  // merge: per row group m[2], l[2] per lane
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hh = lane >> 5;
+  const int rg = __builtin_amdgcn_readfirstlane(wv & 1), kh = __builtin_amdgcn_readfirstlane(wv >> 1);
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = bid % p.nqt, bh = bid / p.nqt;
+  const int head = bh % p.heads, bz = bh / p.heads;
+  const u16* Q = p.q + (long long)bz * p.sq + head * 64;
+  const u16* K = p.k + (long long)bz * p.sk + head * 64;
+  const u16* V = p.v + (long long)bz * p.sv + head * 64;
+  u16* O = p.o + (long long)bz * p.so + head * 64;
+
+  // Q fragments, pre-scaled by scale * log2(e) (one more fp16 rounding of q: the scores then leave the MFMA in the log2 domain)
+  hx8 qf[2][4];
+  int qrow[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qrow[qb] = qt * 128 + rg * 64 + qb * 32 + r;
+    const int qrc = qrow[qb] < p.nq ? qrow[qb] : p.nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const hx8 raw = *(const hx8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
+      if (p.scale_log2 == 1.0f) qf[qb][ks] = raw;  // q already in the log2 domain (sdmi_attention_log2q)
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (h16)((float)raw[j] * p.scale_log2);
+    }
+  }
+  // staging: the two waves of a stream each move 32 rows of K and of V per tile (4 + 4 DMA instructions of 8 rows)
+  const int spos = lane & 7;
+  u16* const sbase = smem + kh * 4 * 4096;  // this stream's [buffer][K | V]
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) u16*)sbase + rg * 4096;  // bytes
+  f32x16 oacc[2][2], negm[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[0][0][i] = oacc[0][1][i] = oacc[1][0][i] = oacc[1][1][i] = 0.f; negm[0][i] = negm[1][i] = 0.f; }
+  float mrun[2] = {0.f, 0.f}, lrun[2] = {0.f, 0.f};
+  const int dblk = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+
+  const int ntiles = (p.nkv + 63) / 64;
+  const int nbar = (ntiles + 1) / 2;  // tiles of the first stream (the longer one): every wave runs nbar + 1 barriers
+  const int t0 = kh ? nbar : 0, t1 = kh ? ntiles : nbar;
+  // per-lane byte offsets of the 4 + 4 pieces inside a tile (full tiles: wave-uniform tile base + these; the last,
+  // partial tile clamps its rows to the last key instead)
+  unsigned offk[4], offv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 32 * rg + 8 * j + (lane >> 3);
+    offk[j] = 2u * (row * p.ldk + (spos ^ ((row >> 1) & 7)) * 8);
+    offv[j] = 2u * (row * p.ldv + (spos ^ (((row >> 1) & 1) << 2)) * 8);
+  }
+  const long long stepk = (long long)128 * p.ldk, stepv = (long long)128 * p.ldv;  // bytes per 64-key tile
+  auto stage_full = [&](int tile, int buf) {
+    const char* kt = (const char*)K + tile * stepk;
+    const char* vt = (const char*)V + tile * stepv;
+    const unsigned dst = lds0 + buf * 16384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      attn2_dma16(kt + offk[j], dst + j * 1024);
+      attn2_dma16(vt + offv[j], dst + 8192 + j * 1024);
+    }
+  };
+  auto stage_tail = [&](int tile, int buf) {
+    const unsigned dst = lds0 + buf * 16384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 32 * rg + 8 * j + (lane >> 3);
+      const int key = min(tile * 64 + row, p.nkv - 1);  // rows past the end repeat the last key (masked in the scores)
+      attn2_dma16(K + (long long)key * p.ldk + (spos ^ ((row >> 1) & 7)) * 8, dst + j * 1024);
+      attn2_dma16(V + (long long)key * p.ldv + (spos ^ (((row >> 1) & 1) << 2)) * 8, dst + 8192 + j * 1024);
+    }
+  };
+  auto stage = [&](int tile, int buf) {
+    if ((tile + 1) * 64 <= p.nkv) stage_full(tile, buf);
+    else stage_tail(tile, buf);
+  };
+#define ATTN2_END_TILE()                                  \
+  {                                                       \
+    __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */     \
+    asm volatile("" ::: "memory");                        \
+    __syncthreads();                                      \
+  }
+  if (t1 > t0) stage(t0, 0);
+  ATTN2_END_TILE();
+  int done = 0;
+  if (t1 > t0) {
+    // first tile of this wave's range: its first block sets the running maximum
+    {
+      if (t0 + 1 < t1) stage(t0 + 1, 1);
+      const u16* cK = sbase;
+      const u16* cV = cK + 4096;
+      const int k0 = t0 * 64;
+      if (k0 + 64 <= p.nkv) {
+        attn2_block<true, false>(cK, cV, 0, qf, oacc, negm, mrun, lrun, k0, p.nkv, r, hh, dblk, tq, tp);
+        attn2_block<false, false>(cK, cV, 1, qf, oacc, negm, mrun, lrun, k0 + 32, p.nkv, r, hh, dblk, tq, tp);
+      } else {
+        attn2_block<true, true>(cK, cV, 0, qf, oacc, negm, mrun, lrun, k0, p.nkv, r, hh, dblk, tq, tp);
+        if (k0 + 32 < p.nkv) attn2_block<false, true>(cK, cV, 1, qf, oacc, negm, mrun, lrun, k0 + 32, p.nkv, r, hh, dblk, tq, tp);
+      }
+      ATTN2_END_TILE();
+      done = 1;
+    }
+    // full tiles
+    const int tfull = min(t1, p.nkv >> 6);
+    int tile = t0 + 1;
+    for (; tile < tfull; ++tile, ++done) {
+      const int buf = done & 1;
+      if (tile + 1 < t1) stage(tile + 1, buf ^ 1);
+      const u16* cK = sbase + buf * 8192;
+      const u16* cV = cK + 4096;
+      attn2_block<false, false>(cK, cV, 0, qf, oacc, negm, mrun, lrun, tile * 64, p.nkv, r, hh, dblk, tq, tp);
+      attn2_block<false, false>(cK, cV, 1, qf, oacc, negm, mrun, lrun, tile * 64 + 32, p.nkv, r, hh, dblk, tq, tp);
+      ATTN2_END_TILE();
+    }
+    if (tile < t1) {  // the partial last tile
+      const u16* cK = sbase + (done & 1) * 8192;
+      const u16* cV = cK + 4096;
+      const int k0 = tile * 64;
+      attn2_block<false, true>(cK, cV, 0, qf, oacc, negm, mrun, lrun, k0, p.nkv, r, hh, dblk, tq, tp);
+      if (k0 + 32 < p.nkv) attn2_block<false, true>(cK, cV, 1, qf, oacc, negm, mrun, lrun, k0 + 32, p.nkv, r, hh, dblk, tq, tp);
+      ATTN2_END_TILE();
+      ++done;
+    }
+  }
+  for (; done < nbar; ++done) ATTN2_END_TILE();
+#undef ATTN2_END_TILE
+
+  // merge: the second stream's waves hand (O, m, l) to the first stream's wave of the same rows, lane to lane, through the
+  // second stream's tile images (every read of them is behind the loop's last barrier)
+  float* mgO = (float*)(smem + 4 * 4096) + rg * 4096;  // 64 accumulator registers x 64 lanes per row group (16 KB)
+  float* mgS = sML[rg];
+  if (kh == 1) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mgO[((qb * 2 + dt) * 16 + i) * 64 + lane] = oacc[qb][dt][i];
+      mgS[qb * 64 + lane] = t1 > t0 ? mrun[qb] : -3.0e38f;  // a stream without tiles weighs nothing
+      mgS[(2 + qb) * 64 + lane] = lrun[qb];
+    }
+  }
+  __syncthreads();
+  if (kh == 1) return;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float m1 = mgS[qb * 64 + lane], l1 = mgS[(2 + qb) * 64 + lane];
+    const float m = fmaxf(mrun[qb], m1);
+    const float a0 = __builtin_amdgcn_exp2f(mrun[qb] - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    const float lsum = lrun[qb] * a0 + l1 * a1;
+    const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
+    const float w0 = a0 * inv, w1 = a1 * inv;
+    if (qrow[qb] < p.nq) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = 32 * dt + 8 * g + 4 * hh;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = oacc[qb][dt][4 * g + e] * w0 + mgO[((qb * 2 + dt) * 16 + 4 * g + e) * 64 + lane] * w1;
+          *(uint2*)(O + (long long)qrow[qb] * p.ldo + d) = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
+        }
+    }
+  }
+}
+
+static int attention_launch(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v, int ldv,
+                            int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv, float scale,
+                            bool log2q, void* stream) {
   SDMI_REQUIRE(q && k && v && o, "attention: null pointer");
   SDMI_REQUIRE(batch > 0 && heads > 0 && nq > 0 && nkv > 0, "attention: bad shape");
   SDMI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: row strides must be multiples of 8");
@@ -225,9 +506,30 @@ extern "C" int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k,
   AttnParams p;
   p.q = (const u16*)q; p.k = (const u16*)k; p.v = (const u16*)v; p.o = (u16*)o;
   p.sq = sq; p.sk = sk; p.sv = sv; p.so = so; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
-  p.nq = nq; p.nkv = nkv; p.scale_log2 = scale * 1.44269504088896340736f;
+  p.nq = nq; p.nkv = nkv; p.scale_log2 = log2q ? 1.0f : scale * 1.44269504088896340736f;
+  // long self-attention: the 64-rows-per-wave structure (attn_variant: -1 never, 1 always, 0 = by shape)
+  const int variant = sdmi_option("attn_variant");
+  if (variant > 0 || (variant == 0 && nkv >= 1024 && nq >= 2048)) {
+    p.nqt = (nq + 127) / 128; p.heads = heads;
+    hipLaunchKernelGGL(attn64x2_kernel, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
+    sdmi_note_kernel("attn64x2_kernel");
+    return sdmi_check_launch("attention (64 rows per wave)");
+  }
   p.nqt = (nq + 127) / 128; p.heads = heads;
   dim3 grid(p.nqt * heads * batch), block(256);
   hipLaunchKernelGGL(attn64_kernel, grid, block, 0, (hipStream_t)stream, p);
+  sdmi_note_kernel("attn64_kernel");
   return sdmi_check_launch("attention");
+}
+
+extern "C" int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
+                              int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv,
+                              float scale, void* stream) {
+  return attention_launch(q, ldq, sq, k, ldk, sk, v, ldv, sv, o, ldo, so, batch, heads, nq, nkv, scale, false, stream);
+}
+
+extern "C" int sdmi_attention_log2q(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
+                                    int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq,
+                                    int nkv, void* stream) {
+  return attention_launch(q, ldq, sq, k, ldk, sk, v, ldv, sv, o, ldo, so, batch, heads, nq, nkv, 1.0f, true, stream);
 }

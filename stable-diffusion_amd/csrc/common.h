@@ -16,11 +16,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 h16;
 #define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
 #define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#define MFMA32_MNEMONIC "v_mfma_f32_32x32x16_bf16"
+#define DOT2H(a, b, c) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false)
 #define SDMI_ACT_DTYPE 1
 #else
 typedef _Float16 h16;
 #define MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
 #define MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#define MFMA32_MNEMONIC "v_mfma_f32_32x32x16_f16"
+#define DOT2H(a, b, c) __builtin_amdgcn_fdot2(a, b, c, false)
 #define SDMI_ACT_DTYPE 0
 #endif
 typedef h16 hx8 __attribute__((ext_vector_type(8)));

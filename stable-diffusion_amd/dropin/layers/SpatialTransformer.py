@@ -108,8 +108,11 @@ class MemoryEfficientCrossAttention(nn.Module):
         token stream and the LayerNorm is folded into the q (|k|v) projection.  rowstats: leave per-row statistics of the
         result for the LayerNorm that follows."""
         inner = 64 * self.heads
-        proj = (lambda ws: E.gemm_ln(a, ln, ws)) if ln is not None else \
-               (lambda ws: E.gemm(a, E.packed_linear(ws), sum(w.shape[0] for w in ws)))
+        # the query projection carries 1/8 * log2(e), folded into to_q before its rounding to 16 bits: scores leave the
+        # QK^T MFMAs in the log2 domain (sdmi_attention_log2q)
+        qs = lambda ws: (E.Q_LOG2_SCALE,) + (None,) * (len(ws) - 1)
+        proj = (lambda ws: E.gemm_ln(a, ln, ws, scales=qs(ws))) if ln is not None else \
+               (lambda ws: E.gemm(a, E.packed_linear(ws, scales=qs(ws)), sum(w.shape[0] for w in ws)))
         if context is None:          # self-attention: one fused q|k|v GEMM
             if self.to_k.weight.shape[1] != a.c:
                 raise E.L.SdmiError("attention without context: to_k expects %d channels, the tokens have %d (the reference "
@@ -123,7 +126,7 @@ class MemoryEfficientCrossAttention(nn.Module):
             else:
                 kv = E.gemm(context, E.packed_linear((self.to_k.weight, self.to_v.weight)), 2 * inner)
             k, v = kv.cols(0, inner), kv.cols(inner, inner)
-        o = E.attention(q, k, v, self.heads)
+        o = E.attention(q, k, v, self.heads, log2q=True)
         lin = self.to_out[0]
         return E.gemm(o, E.packed_linear((lin.weight,)), lin.weight.shape[0], bias=lin.bias, residual=residual, rowstats=rowstats)
 

@@ -143,21 +143,32 @@ def packed_conv3x3(weight):
     return PACK.get((weight,), "c3", build)
 
 
-def packed_linear(weights, geglu=False):
-    """One or more (N_i, K[,1,1]) fp32 weights stacked along N -> bf16 [sum N_i][K]."""
+# softmax(q k^T / 8) in base 2: the factor the query projection carries when attention runs on sdmi_attention_log2q
+Q_LOG2_SCALE = 0.125 * 1.4426950408889634
+
+
+def _scaled(w, scale):
+    """fp32 weight times a per-projection constant, before the single rounding to 16 bits (pack time only)."""
+    return w if scale is None or scale == 1.0 else (w * scale).contiguous()
+
+
+def packed_linear(weights, geglu=False, scales=None):
+    """One or more (N_i, K[,1,1]) fp32 weights stacked along N -> bf16 [sum N_i][K].  scales: one constant per weight,
+    multiplied in before rounding (the query projection's scale * log2(e))."""
     weights = tuple(weights)
+    scales = tuple(scales) if scales is not None else (None,) * len(weights)
 
     def build():
         k = weights[0].shape[1]
         ntot = sum(w.shape[0] for w in weights)
         out = torch.empty((ntot, k), dtype=act_dtype(), device=weights[0].device)
         r = 0
-        for w in weights:
-            w = _f32c(w, "linear weight")
-            L.call("sdmi_pack_linear", w.data_ptr(), out.data_ptr() + 2 * r * k, w.shape[0], k, 1 if geglu else 0, _stream())
+        for w, sc in zip(weights, scales):
+            ws = _scaled(_f32c(w, "linear weight"), sc)
+            L.call("sdmi_pack_linear", ws.data_ptr(), out.data_ptr() + 2 * r * k, w.shape[0], k, 1 if geglu else 0, _stream())
             r += w.shape[0]
         return out
-    return PACK.get(weights, "lg" if geglu else "l", build)
+    return PACK.get(weights, ("lg" if geglu else "l") + repr(scales if any(scales) else ""), build)
 
 
 def stacked_f32(params):
@@ -367,13 +378,16 @@ def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shap
     return res
 
 
-def packed_linear_ln(weights, ln_weight, ln_bias, bias=None, geglu=False):
+def packed_linear_ln(weights, ln_weight, ln_bias, bias=None, geglu=False, scales=None):
     """Weights of the Linear(s) that follow a LayerNorm, with the LayerNorm folded in (sdmi_pack_linear_ln): returns
     (packed h16 [sum N_i][K] with gamma folded, u fp32 [sum N_i] in packed row order, v fp32 [sum N_i] = beta.W + bias)."""
     weights = tuple(weights)
     biases = tuple(bias) if isinstance(bias, (tuple, list)) else ((bias,) if bias is not None else ())
     if geglu and len(weights) != 1:
         raise L.SdmiError("packed_linear_ln: GEGLU packs one weight")
+    scales = tuple(scales) if scales is not None else (None,) * len(weights)
+    if biases and any(scales):
+        raise L.SdmiError("packed_linear_ln: scaled projections carry no bias")
 
     def build():
         k = weights[0].shape[1]
@@ -385,36 +399,42 @@ def packed_linear_ln(weights, ln_weight, ln_bias, bias=None, geglu=False):
         g, b = _f32c(ln_weight, "ln weight"), _f32c(ln_bias, "ln bias")
         r = 0
         for i, w in enumerate(weights):
-            w = _f32c(w, "linear weight")
+            ws = _scaled(_f32c(w, "linear weight"), scales[i])
             bi = _f32c(biases[i], "linear bias").data_ptr() if biases else 0
-            L.call("sdmi_pack_linear_ln", w.data_ptr(), g.data_ptr(), b.data_ptr(), bi, wp.data_ptr() + 2 * r * k,
+            L.call("sdmi_pack_linear_ln", ws.data_ptr(), g.data_ptr(), b.data_ptr(), bi, wp.data_ptr() + 2 * r * k,
                    u.data_ptr() + 4 * r, v.data_ptr() + 4 * r, w.shape[0], k, 1 if geglu else 0, _stream())
             r += w.shape[0]
         return wp, u, v
-    return PACK.get(weights + (ln_weight, ln_bias) + biases, "lnl" + ("g" if geglu else ""), build)
+    return PACK.get(weights + (ln_weight, ln_bias) + biases,
+                    "lnl" + ("g" if geglu else "") + repr(scales if any(scales) else ""), build)
 
 
-def gemm_ln(a, ln_mod, weights, bias=None, geglu=False, **kw):
+def gemm_ln(a, ln_mod, weights, bias=None, geglu=False, scales=None, **kw):
     """LayerNorm(a) @ W^T (+bias): folded into one GEMM when `a` carries row statistics from its producer (gemm(...,
     rowstats=True)), else the LayerNorm kernel followed by the plain GEMM."""
     weights = tuple(weights)
     n_out = sum(w.shape[0] for w in weights)
     if USE_LNFOLD and a.rstats is not None:
-        wp, u, v = packed_linear_ln(weights, ln_mod.weight, ln_mod.bias, bias, geglu)
+        wp, u, v = packed_linear_ln(weights, ln_mod.weight, ln_mod.bias, bias, geglu, scales)
         return gemm(a, wp, n_out, bias=v, geglu=geglu, ln=(u, ln_mod.eps), **kw)
     x = layernorm(a, ln_mod.weight, ln_mod.bias, ln_mod.eps)
     b = stacked_f32(tuple(bias)) if isinstance(bias, (tuple, list)) else bias
-    return gemm(x, packed_linear(weights, geglu=geglu), n_out, bias=b, geglu=geglu, **kw)
+    return gemm(x, packed_linear(weights, geglu=geglu, scales=scales), n_out, bias=b, geglu=geglu, **kw)
 
 
-def attention(q, k, v, heads, out=None):
-    """softmax(q k^T / 8) v per head; q/k/v are column views (Act.cols) of token buffers."""
+def attention(q, k, v, heads, out=None, log2q=False):
+    """softmax(q k^T / 8) v per head; q/k/v are column views (Act.cols) of token buffers.  log2q: q already carries
+    Q_LOG2_SCALE (folded into the to_q weights at pack time)."""
     o = out if out is not None else new_act(q.n, q.h, q.w, heads * 64, q.device)
     if (o.n, o.hw, o.c) != (q.n, q.hw, heads * 64) or (k.n, v.n, v.hw) != (q.n, q.n, k.hw):
         raise L.SdmiError("attention: q (%d,%d) / k (%d,%d) / v (%d,%d) / out (%d,%d,%d) do not match" %
                           (q.n, q.hw, k.n, k.hw, v.n, v.hw, o.n, o.hw, o.c))
-    L.call("sdmi_attention", q.ptr, q.ld, q.hw * q.ld, k.ptr, k.ld, k.hw * k.ld, v.ptr, v.ld, v.hw * v.ld,
-           o.ptr, o.ld, o.hw * o.ld, q.n, heads, q.hw, k.hw, 0.125, _stream())
+    args = (q.ptr, q.ld, q.hw * q.ld, k.ptr, k.ld, k.hw * k.ld, v.ptr, v.ld, v.hw * v.ld,
+            o.ptr, o.ld, o.hw * o.ld, q.n, heads, q.hw, k.hw)
+    if log2q:
+        L.call("sdmi_attention_log2q", *(args + (_stream(),)))
+    else:
+        L.call("sdmi_attention", *(args + (0.125, _stream())))
     return o
 
 

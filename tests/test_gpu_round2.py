@@ -299,3 +299,80 @@ def test_resblock_large_vs_oracle_with_colstats(hh, cin, cout):
             E.USE_COLSTATS = saved
     _gate(outs[True], ref, 4e-3, 1.5e-3, "ResBlock %dx%d %d->%d (colstats)" % (hh, hh, cin, cout))
     _gate(outs[False], ref, 4e-3, 1.5e-3, "  re-reading path")
+
+
+# ------------------------------------------------------------------ attention: the 64-rows-per-wave kernel (KV split in two)
+def _attn_ref(q, k, v, heads, scale=0.125):
+    b, nq, c = q.shape
+    sp = lambda t: t.double().reshape(b, t.shape[1], heads, 64).permute(0, 2, 1, 3)
+    a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * scale, dim=-1) @ sp(v)
+    return a.permute(0, 2, 1, 3).reshape(b, nq, c)
+
+
+@pytest.fixture
+def attn_variant():
+    lib = L.load()
+    yield lambda v: lib.sdmi_set_option(b"attn_variant", v)
+    lib.sdmi_set_option(b"attn_variant", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,heads,nq,nkv,kind", [
+    (1, 1, 64, 31, "plain"),        # one partial tile: the second key stream has no tiles at all
+    (1, 2, 130, 64, "plain"),       # exactly one full tile
+    (1, 2, 130, 65, "plain"),       # second stream = one key
+    (2, 3, 257, 77, "plain"),       # the cross-attention shape, ragged rows
+    (1, 2, 300, 96, "plain"),       # second stream = half a tile
+    (1, 2, 1000, 1111, "plain"),
+    (1, 2, 512, 640, "late_spike"),  # one key far above the rest late in the second stream: the deferred maximum must move
+    (1, 2, 512, 640, "early_spike"),
+    (1, 2, 2304, 2304, "wide"),     # logits of about +-200
+])
+def test_attention_kv_split_kernel_vs_fp64(attn_variant, b, heads, nq, nkv, kind):
+    """attn64x2_kernel forced on shapes its dispatch rule (nq >= 2048, nkv >= 1024) would not pick: empty / one-key / ragged
+    second stream, rows past nq, running-maximum jumps; against the fp64 definition, both entry points, and against the
+    32-rows-per-wave kernel.  Gate 6e-4 rel-L2 as for sdmi_attention everywhere else (fp16 P and V roundings)."""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(nq * 7 + nkv)
+    c = heads * 64
+    q, k, v = (torch.randn(b, n, c, generator=g).to(dev) for n in (nq, nkv, nkv))
+    if kind == "late_spike":
+        k[:, 600] = q[:, 7] * 3.0
+    if kind == "early_spike":
+        k[:, 3] = q[:, 7] * 3.0
+    if kind == "wide":
+        q *= 5.0
+        k *= 5.0
+    H = E.act_dtype()
+    mk = lambda t: E.Act(t.contiguous(), t.shape[0], 1, t.shape[1], t.shape[2])
+    qh, kh, vh = q.to(H), k.to(H), v.to(H)
+    ql = (q * E.Q_LOG2_SCALE).to(H)              # what a to_q with the folded factor delivers: one rounding
+    want = _attn_ref(qh, kh, vh, heads)
+    want_l = _attn_ref(ql.double() / E.Q_LOG2_SCALE, kh, vh, heads)
+    outs = {}
+    for variant in (-1, 1):
+        attn_variant(variant)
+        outs[variant] = E.attention(mk(qh), mk(kh), mk(vh), heads).buf.double()
+        outs[variant, "l"] = E.attention(mk(ql), mk(kh), mk(vh), heads, log2q=True).buf.double()
+        assert L.load().sdmi_last_kernel().decode() == ("attn64x2_kernel" if variant == 1 else "attn64_kernel")
+    # log2q: q is exact in the kernel, same error budget as the 32-row kernel; scale path: q is re-rounded after scaling,
+    # which costs precision with wide logits (the UNet does not use that path on this kernel)
+    l2 = lambda a, b_: float((a - b_).norm() / b_.norm())
+    assert l2(outs[-1], want) < 6e-4 and l2(outs[-1, "l"], want_l) < 6e-4
+    assert l2(outs[1, "l"], want_l) < 6e-4
+    assert l2(outs[1, "l"], outs[-1, "l"]) < 6e-4
+    assert l2(outs[1], want) < (6e-4 if kind != "wide" else 2.5e-3)
+    assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[1, "l"]).all()
+
+
+@pytest.mark.gpu
+def test_attention_dispatch_long_self_attention_uses_kv_split_kernel():
+    dev = torch.device("cuda", 0)
+    H = E.act_dtype()
+    t = torch.randn(1, 2304, 128, device=dev).to(H)
+    a = E.Act(t, 1, 1, 2304, 128)
+    E.attention(a, a, a, 2, log2q=True)
+    assert L.load().sdmi_last_kernel().decode() == "attn64x2_kernel"
+    s = torch.randn(1, 77, 128, device=dev).to(H)
+    E.attention(a, E.Act(s, 1, 1, 77, 128), E.Act(s, 1, 1, 77, 128), 2, log2q=True)
+    assert L.load().sdmi_last_kernel().decode() == "attn64_kernel"
