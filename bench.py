@@ -72,7 +72,7 @@ def build_models(dev, seed=0):
     return unet, vae
 
 
-def cpu_baseline(unet, vae, L, steps, threads):
+def cpu_baseline(unet, vae, L, steps, threads, mode="sample"):
     """The oracle (fp32 torch restatement == reference arithmetic) on the host cores: one UNet step (CFG batch 2) and
     one decode at the benchmark resolution, extrapolated to steps x UNet + 1 decode."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -83,6 +83,11 @@ def cpu_baseline(unet, vae, L, steps, threads):
     f32 = lambda *s: torch.from_numpy(rs.randn(*s).astype(np.float32))
     x, ctx, t = f32(2, 9, L, L), f32(2, 77, 1024), torch.tensor([501, 501])
     with torch.no_grad():
+        if mode == "decode":
+            z = f32(1, 4, L, L)
+            t0 = time.perf_counter(); O.vae_decode(sd_v, z); t_dec = time.perf_counter() - t0
+            return {"value": 1.0 / t_dec, "unit": "images/s", "cores": threads, "kind": "port",
+                    "sample": "1 decode (%.2f s) at %dx%d, fp32 oracle" % (t_dec, 8 * L, 8 * L), "decode_s": t_dec}
         t0 = time.perf_counter(); O.unet_forward(sd_u, x, t, ctx); t_unet = time.perf_counter() - t0
         z = f32(1, 4, L, L)
         t0 = time.perf_counter(); O.vae_decode(sd_v, z); t_dec = time.perf_counter() - t0
@@ -102,6 +107,9 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--scale", type=float, default=9.0)
+    ap.add_argument("--mode", choices=["sample", "decode"], default="sample",
+                    help="sample: the full inpainting job (BASELINE configs 2-4); decode: AutoencoderKL.decode of --batch "
+                         "latents per step, uint8 images out (BASELINE config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -126,7 +134,7 @@ def main():
     unet_cpu, vae_cpu = build_models(dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(unet_cpu, vae_cpu, L, args.ddim_steps, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+        cpu = cpu_baseline(unet_cpu, vae_cpu, L, args.ddim_steps, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))), args.mode)
     unet, vae = unet_cpu.to(dev), vae_cpu.to(dev)
     inp = make_inputs(b, L, args.ddim_steps, seed=100 + rank)
     g = lambda t: t.to(dev)
@@ -146,7 +154,10 @@ def main():
         return
 
     def one_step():
-        _, img = sampler.sample(args.ddim_steps, cond, uncond, c_concat, x_T, noises, args.scale, use_graph=not args.no_graph)
+        if args.mode == "decode":
+            img = sampler.decode_to_uint8(x_T, use_graph=not args.no_graph)
+        else:
+            _, img = sampler.sample(args.ddim_steps, cond, uncond, c_concat, x_T, noises, args.scale, use_graph=not args.no_graph)
         return all_gather_images(img, total)
 
     def barrier():
@@ -169,19 +180,21 @@ def main():
         dt = float(tt.item())
 
     # UNet step latency (graph replay of one forward, CFG batch 2b) on its own
-    xc = torch.randn((b, 9, L, L), device=dev).repeat(2, 1, 1, 1)   # CFG: both halves see the same latent and conditioning
-    tb = torch.full((2 * b,), 501, dtype=torch.long, device=dev)
-    cc = sampler.make_context(uncond, cond)
-    tb = unet.precompute_time_embedding(tb)   # as the sampling loop runs it: the t-only MLPs are hoisted out of the step
-    sampler._unet_step(xc, tb, cc, not args.no_graph, same_halves=True)
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
+    unet_ms = None
+    if args.mode == "sample":
+        xc = torch.randn((b, 9, L, L), device=dev).repeat(2, 1, 1, 1)   # CFG: both halves see the same latent and conditioning
+        tb = torch.full((2 * b,), 501, dtype=torch.long, device=dev)
+        cc = sampler.make_context(uncond, cond)
+        tb = unet.precompute_time_embedding(tb)   # as the sampling loop runs it: the t-only MLPs are hoisted out of the step
         sampler._unet_step(xc, tb, cc, not args.no_graph, same_halves=True)
-    e1.record()
-    torch.cuda.synchronize()
-    unet_ms = e0.elapsed_time(e1) / 10
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            sampler._unet_step(xc, tb, cc, not args.no_graph, same_halves=True)
+        e1.record()
+        torch.cuda.synchronize()
+        unet_ms = e0.elapsed_time(e1) / 10
     sampler.decode_to_uint8(x_T, use_graph=not args.no_graph)
     torch.cuda.synchronize()
     e0.record()
@@ -189,6 +202,16 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     dec_ms = e0.elapsed_time(e1)
+
+    # FLOPs the job actually executes (the CFG halves share a prefix that runs once; algorithmic figure beside it): the
+    # work_of() sum over the C-ABI launches of one eager UNet step in the sampler's own execution form, and of one decode
+    def executed_gflop(fn):
+        with _lib.KernelTimer(work_of) as kt:
+            fn()
+        torch.cuda.synchronize()
+        return sum(w[0] for _, w, _, _ in kt.records) / 1e9
+    exec_unet = executed_gflop(lambda: sampler._unet_step(xc, tb, cc, False, same_halves=True)) if args.mode == "sample" else 0.0
+    exec_dec = executed_gflop(lambda: sampler.decode_to_uint8(x_T, use_graph=False))
 
     def measured_peaks():
         """MFMA issue rate (v_mfma_f32_32x32x16 only, two waves per SIMD) and streaming-copy bandwidth of THIS box."""
@@ -214,8 +237,9 @@ def main():
         return {"mfma_tflops": mfma, "hbm_copy_gbs": hbm}
 
     roof, kernels = None, None
-    traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    pmc_traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r02_traffic.json", "r01_traffic.json"))
+                         if os.path.exists(f)), None)
+    pmc_traffic = json.load(open(traffic_file)) if traffic_file else {}
 
     def traffic_of(kernel):
         """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md
@@ -234,12 +258,14 @@ def main():
         # The per-kernel figures are taken with the CFG batch [uncond | cond] as ONE pass on one stream: the sampling loop
         # runs the same kernels as two concurrent batch-1 passes (same bits), where a kernel's event pair would also
         # time whatever the other stream runs beside it.
-        cc1 = unet.precompute_context(torch.cat([uncond, cond]).contiguous())
-        unet(xc, timesteps=tb, context=cc1)   # warm-up of the batch-2 shapes
-        torch.cuda.synchronize()
+        if args.mode == "sample":
+            cc1 = unet.precompute_context(torch.cat([uncond, cond]).contiguous())
+            unet(xc, timesteps=tb, context=cc1)   # warm-up of the batch-2 shapes
+            torch.cuda.synchronize()
         with _lib.KernelTimer(work_of) as kt:
-            torch.cuda._sleep(int(60e6))
-            unet(xc, timesteps=tb, context=cc1)
+            if args.mode == "sample":
+                torch.cuda._sleep(int(60e6))
+                unet(xc, timesteps=tb, context=cc1)
             n_unet = len(kt.records)
             zdec = x_T / 0.18215
             torch.cuda.synchronize()
@@ -265,6 +291,8 @@ def main():
                     "frac": ach / PEAK_HBM_GBS, "traffic": traffic_of(dom), "avg_launch_ms": d["ms"] / d["launches"],
                     "launches_per_image": d["launches"], "share_of_image_time": d["ms"] / sum(v["ms"] for v in tot.values())}
         # the same fraction against what this box measures: `peak` / `frac` above stay the nominal ones
+        roof["traffic_source"] = ("committed PMC passes, %s (not re-measured in this run)" % os.path.relpath(traffic_file, ROOT)
+                                  if roof["traffic"] is not None else None)
         mp = measured_peaks()
         roof["peak_measured"] = mp["mfma_tflops"] if roof["bound"] == "mfma" else mp["hbm_copy_gbs"]
         roof["frac_of_measured"] = roof["achieved"] / roof["peak_measured"]
@@ -275,20 +303,35 @@ def main():
                    for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
 
     if rank == 0:
-        gflop_img = args.ddim_steps * UNET_GFLOP.get(L, 0.0) + DECODE_GFLOP.get(L, 0.0)
+        if args.mode == "decode":
+            gflop_img, gflop_exec = DECODE_GFLOP.get(L, 0.0), exec_dec / b
+            workload = ("AutoencoderKL.decode %dx%d, batch %d per GPU, latents -> uint8 HWC images, random-init weights at "
+                        "checkpoint shapes" % (args.res, args.res, b))
+            metric = "images/sec (whole node) VAE decode %dx%d" % (args.res, args.res)
+        else:
+            gflop_img = args.ddim_steps * UNET_GFLOP.get(L, 0.0) + DECODE_GFLOP.get(L, 0.0)
+            gflop_exec = (args.ddim_steps * exec_unet + exec_dec) / b
+            workload = ("SD-2 inpainting %dx%d, batch %d per GPU, %d DDIM steps, CFG scale %g, UNet + fused CFG/DDIM update + "
+                        "AutoencoderKL decode, random-init weights at checkpoint shapes" % (args.res, args.res, b, args.ddim_steps, args.scale))
+            metric = "images/sec (whole node) %dx%d %d-step inpaint; UNet step latency ms" % (args.res, args.res, args.ddim_steps)
         line = {
-            "metric": "images/sec (whole node) 768x768 50-step inpaint; UNet step latency ms",
+            "metric": metric,
             "value": total * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if E.act_dtype() == torch.float16 else "bf16", "data": "synthetic",
-            "config": {"workload": "SD-2 inpainting %dx%d, batch %d per GPU, %d DDIM steps, CFG scale %g, UNet + fused CFG/DDIM "
-                                   "update + AutoencoderKL decode, random-init weights at checkpoint shapes" % (args.res, args.res, b, args.ddim_steps, args.scale),
+            "config": {"workload": workload, "mode": args.mode,
                        "resolution": args.res, "batch_per_gpu": b, "ddim_steps": args.ddim_steps, "guidance_scale": args.scale,
                        "parallelism": "images sharded dp%d, one all-gather of uint8 outputs" % world,
                        "hip_graph": not args.no_graph},
             "unet_step_ms": unet_ms, "decode_ms": dec_ms,
-            "mfma_frac_end_to_end": (gflop_img * b / 1e3) / (dt / args.steps) / PEAK_MFMA_TFLOPS if gflop_img else None,
+            # executed: what the launches of this run compute (shared CFG prefix once); algorithmic: SURVEY 8(a) per image
+            "mfma_frac_end_to_end": (gflop_exec * b / 1e3) / (dt / args.steps) / PEAK_MFMA_TFLOPS,
+            "mfma_frac_algorithmic": (gflop_img * b / 1e3) / (dt / args.steps) / PEAK_MFMA_TFLOPS if gflop_img else None,
+            "gflop_per_image": {"executed": gflop_exec, "algorithmic": gflop_img or None},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "kernels_note": "HIP-event pairs around every C-ABI launch of ONE eager batch-%d UNet step (x%d) + one decode on one "
+                            "stream; a ranking, not an accounting of the graph-replayed two-stream loop (rocprofv3 window of "
+                            "the same pass: profiles/r02_roofline_pass_kernel_stats.csv)" % (2 * b, args.ddim_steps),
         }
         print(json.dumps(line))
     if world > 1:

@@ -219,6 +219,23 @@ int sdmi_attention_log2q(const void* q, int ldq, int64_t sq, const void* k, int 
  *      score GEMM -> this -> value GEMM).  x fp32 [rows][ldx] -> y bf16 [rows][ldy], y = softmax(x*scale). */
 int sdmi_softmax_rows(const float* x, int ldx, void* y, int ldy, int rows, int cols, float scale, void* stream);
 
+/* ---- inpainting pre-processing: pad_image + make_batch_sd + the mask branch of inpaint()'s c_cat loop
+ *      (LatentDiffusionInpainting.py:58-63, :65-89, :281-285) in one pass.  image uint8 HWC (h0, w0, 3); mask uint8
+ *      (h0, w0, mask_channels), 3 = RGB (reduced to PIL's "L"), 1 = L; (h, w) the padded size (edge padding on the
+ *      bottom / right, as np.pad(mode='edge')).  Outputs, each optional (NULL = skip), fp32 NCHW repeated num_samples
+ *      times: image = px / 127.5 - 1, mask = (L / 255 >= 0.5), masked_image = image * (mask < 0.5), and mask_latent =
+ *      F.interpolate(mask, (h/8, w/8)) (nearest) written at mask_latent + s * mask_latent_stride (floats; e.g. channel 0
+ *      of the (n, 5, h/8, w/8) c_concat tensor).  Exact fp32 arithmetic: bit-identical to the reference's host code. */
+int sdmi_inpaint_prepare(const void* image_hwc_u8, const void* mask_u8, int h0, int w0, int mask_channels, int h, int w,
+                         int num_samples, float* image, float* mask, float* masked_image, float* mask_latent,
+                         int64_t mask_latent_stride, void* stream);
+
+/* ---- posterior sample of the VAE encoder times the latent scale: AutoencoderKL.py:8-21 (clamp, exp(0.5 logvar),
+ *      mean + std * noise) and LatentDiffusionInpainting.py:289-291.  moments fp32 (n, 8, h, w) = [mean | logvar]; noise
+ *      fp32 (n, 4, h, w); out + s * out_sample_stride receives sample s's 4 channels (channels 1..4 of c_concat). */
+int sdmi_posterior_sample(const float* moments, const float* noise, float scale, float* out, int64_t out_sample_stride,
+                          int n, int hw, void* stream);
+
 /* ---- fused classifier-free guidance + DDIM update: LatentDiffusionInpainting.py:198-212.
  *   eps fp32 NCHW (2b,4,h,w) = [uncond | cond]; x, noise fp32 (b,4,h,w); coef = {sqrt_one_minus_at, a_t,
  *   a_prev, sigma_t} as the fp32 values torch.full() would hold; writes x_out (may alias x), pred_x0

@@ -44,7 +44,7 @@ def _load_reference_sampler():
     tree = ast.parse(src)
     keep = []
     for node in tree.body:
-        if isinstance(node, ast.FunctionDef) and node.name in ("to_device", "noise_like"):
+        if isinstance(node, ast.FunctionDef) and node.name in ("to_device", "noise_like", "pad_image", "make_batch_sd"):
             keep.append(node)
         if isinstance(node, ast.ClassDef) and node.name == "GPUManager":
             keep.append(node)
@@ -66,7 +66,7 @@ def _load_reference_sampler():
     import functools
     from PIL import Image
     ns = {"torch": TorchOnCpu(), "nn": torch.nn, "np": np, "partial": functools.partial,
-          "tqdm": lambda it, **kw: it, "Image": Image, "time": __import__("time"), "print": lambda *a, **k: None}
+          "tqdm": lambda it, **kw: it, "Image": Image, "repeat": __import__("einops").repeat, "time": __import__("time"), "print": lambda *a, **k: None}
     exec(compile(mod, "<reference sampler>", "exec"), ns)
     return ns
 
@@ -118,6 +118,36 @@ def reference_schedules(ns, step_counts):
     return g8
 
 
+def reference_preprocess(ns):
+    """G9: the reference's own pad_image() and make_batch_sd() (compiled from its source) on a small odd-sized RGB image
+    and an RGB mask with greys around the 0.5 threshold and coloured pixels (PIL's L conversion); plus the mask branch of
+    inpaint()'s c_cat loop (F.interpolate to H/8 x W/8, LatentDiffusionInpainting.py:283-285).  The oracle's restatements
+    are asserted identical."""
+    from PIL import Image
+    rs = np.random.RandomState(9)
+    w0, h0 = 150, 97
+    img = rs.randint(0, 256, size=(h0, w0, 3)).astype(np.uint8)
+    msk = np.zeros((h0, w0, 3), dtype=np.uint8)
+    msk[20:70, 30:120] = 255
+    msk[5:15, 5:60] = rs.randint(120, 136, size=(10, 55, 1)).astype(np.uint8)        # greys around 127.5
+    msk[75:95, 100:150] = rs.randint(0, 256, size=(20, 50, 3)).astype(np.uint8)       # coloured: exercises RGB -> L
+    pim, pmk = ns["pad_image"](Image.fromarray(img)), ns["pad_image"](Image.fromarray(msk))
+    batch = ns["make_batch_sd"](pim, pmk, txt="a prompt", num_samples=2)
+    w, h = pim.size
+    mask_lat = torch.nn.functional.interpolate(batch["mask"].float(), size=(h // 8, w // 8))
+    opim, opmk = O.pad_image(Image.fromarray(img)), O.pad_image(Image.fromarray(msk))
+    assert np.array_equal(np.array(opim), np.array(pim)) and np.array_equal(np.array(opmk), np.array(pmk))
+    ob = O.make_batch_sd(opim, opmk, txt="a prompt", num_samples=2)
+    for k in ("image", "mask", "masked_image"):
+        assert torch.equal(ob[k], batch[k]), k
+        assert torch.equal(batch[k][0], batch[k][1])
+    assert ob["txt"] == batch["txt"]
+    print("  pad_image %dx%d -> %dx%d, make_batch_sd: oracle identical to the reference" % (w0, h0, w, h))
+    return {"image_u8": img, "mask_u8": msk, "padded_image_u8": np.array(pim), "padded_mask_u8": np.array(pmk),
+            "image": _np(batch["image"][:1]), "mask": _np(batch["mask"][:1]), "masked_image": _np(batch["masked_image"][:1]),
+            "mask_latent": _np(mask_lat[:1]), "num_samples": np.array(2)}
+
+
 def _close(a, b, what, tol=2e-5):
     d = (a - b).abs().max().item()
     s = b.abs().max().item()
@@ -138,6 +168,9 @@ def _csum(sd):
 def main():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    if "--only-g9" in sys.argv:       # regenerate the pre-processing fixture alone (seconds)
+        np.savez_compressed(os.path.join(OUT, "g9_preprocess.npz"), **reference_preprocess(_load_reference_sampler()))
+        return
     if "--only-g8" in sys.argv:       # regenerate the schedule fixture alone (seconds)
         np.savez(os.path.join(OUT, "g8_schedule.npz"), **reference_schedules(_load_reference_sampler(), (10, 45, 50)))
         return
@@ -296,6 +329,7 @@ def main():
              traj=np.stack([_np(t) for t in ref_traj]), image=ref_img)
     # schedules for the step counts the configs use: same code path as the one just proven identical
     np.savez(os.path.join(OUT, "g8_schedule.npz"), **g8)
+    np.savez_compressed(os.path.join(OUT, "g9_preprocess.npz"), **reference_preprocess(ns))
     print("golden fixtures written to", OUT)
 
 

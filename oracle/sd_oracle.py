@@ -249,6 +249,41 @@ def gaussian_sample(moments, noise):
     return mean + torch.exp(0.5 * logvar) * noise
 
 
+# --------------------------------------------------------------------------- pre-processing
+def pad_image(input_image):
+    """pad_image (LatentDiffusionInpainting.py:58-63): PIL image -> PIL image padded on the bottom / right by edge
+    replication to the next multiple of 64, at least 128 on each side."""
+    from PIL import Image
+    pad_w, pad_h = np.max(((2, 2), np.ceil(np.array(input_image.size) / 64).astype(int)), axis=0) * 64 - input_image.size
+    return Image.fromarray(np.pad(np.array(input_image), ((0, pad_h), (0, pad_w), (0, 0)), mode='edge'))
+
+
+def make_batch_sd(image, mask, txt, num_samples=1):
+    """make_batch_sd (LatentDiffusionInpainting.py:65-89) on PIL images; `repeat(x, "1 ... -> n ...")` restated with
+    torch.repeat (einops is not needed for a leading-axis repeat)."""
+    image = np.array(image.convert("RGB"))
+    image = image[None].transpose(0, 3, 1, 2)
+    image = torch.from_numpy(image).to(dtype=torch.float32) / 127.5 - 1.0
+    mask = np.array(mask.convert("L"))
+    mask = mask.astype(np.float32) / 255.0
+    mask = mask[None, None]
+    mask[mask < 0.5] = 0
+    mask[mask >= 0.5] = 1
+    mask = torch.from_numpy(mask)
+    masked_image = image * (mask < 0.5)
+    rep = lambda t: t.repeat(num_samples, 1, 1, 1)
+    return {"image": rep(image), "txt": num_samples * [txt], "mask": rep(mask), "masked_image": rep(masked_image)}
+
+
+def image_conditioning(sd_vae, batch, noise, scale_factor=0.18215):
+    """The c_cat loop of inpaint() (LatentDiffusionInpainting.py:279-293) with the posterior's randn injected:
+    [nearest-resized mask | scale_factor * encode(masked_image).sample()]."""
+    h, w = batch["mask"].shape[-2:]
+    mask_lat = F.interpolate(batch["mask"].float(), size=(h // 8, w // 8))
+    lat = scale_factor * gaussian_sample(vae_encode_moments(sd_vae, batch["masked_image"].float()), noise)
+    return torch.cat([mask_lat, lat], dim=1)
+
+
 # --------------------------------------------------------------------------- sampler
 def ddim_schedule(num_ddim_timesteps, eta=1.0, num_train=1000, linear_start=1e-4, linear_end=2e-2):
     """Timesteps and per-step coefficients exactly as LatentDiffusionInpainting.py:125-135, :150-159

@@ -61,6 +61,8 @@ PROTOTYPES = {
     "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
     "sdmi_timestep_embedding": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),
+    "sdmi_inpaint_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sdmi_posterior_sample": (_i, [_vp, _vp, _f, _vp, _i64, _i, _i, _vp]),
     "sdmi_attention_log2q": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "sdmi_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "sdmi_cfg_ddim_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -124,7 +126,7 @@ class KernelTimer(object):
 def call(name, *args):
     """Invoke an int-returning entry point; raise SdmiError(sdmi_last_error()) on a non-zero code."""
     lib = load()
-    if TIMER is not None:
+    if TIMER is not None and not name.endswith(("_stats_parts", "_bytes")):    # host-side size queries launch nothing
         import torch
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -44,6 +44,7 @@ extern "C" const char* sdmi_last_error(void) { return g_err; }
 // runs on different boxes.
 #include <string.h>
 static struct { const char* name; int value; } g_options[] = {
+    {"conv_nmajor_by_rows", 0}, // 1: conv tile order by N > M as in round 1 (0: by operand bytes, 9 N > M)
     {"gemm_small_m_tile", 1},   // 1: 64x64 tiles for K >= 2048 GEMMs with fewer than 1024 rows (0: 64x128 as in round 1)
     {"attn_variant", 0},        // attention kernel variant (0 = default)
 };

@@ -262,3 +262,80 @@ extern "C" int sdmi_timestep_embedding(const int64_t* t, const float* freqs, flo
                      freqs, out, m, half);
   return sdmi_check_launch("timestep_embedding");
 }
+
+// ------------------------------------------------------------------------------------------ inpainting pre-processing
+// pad_image + make_batch_sd + the mask branch of inpaint()'s c_cat loop (LatentDiffusionInpainting.py:58-89, :281-285) in one
+// pass over the padded image: edge padding to (H, W), image / 127.5 - 1, mask -> L -> {0, 1}, image * (mask < 0.5), the
+// repeat over num_samples, and the nearest-neighbour resize of the mask to (H/8, W/8) (F.interpolate's default picks
+// source pixel (8i, 8j)).  Every value is exact fp32 arithmetic on uint8 inputs: bit-identical to the reference's numpy /
+// torch host code.
+__global__ __launch_bounds__(256) void inpaint_prepare_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ msk,
+                                                              int h0, int w0, int mc, int H, int W, int n,
+                                                              float* __restrict__ image_out, float* __restrict__ mask_out,
+                                                              float* __restrict__ masked_out, float* __restrict__ mask_lat,
+                                                              long long mask_lat_stride) {
+  const long long hw = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long long)gridDim.x * 256) {
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    const int ys = y < h0 ? y : h0 - 1, xs = x < w0 ? x : w0 - 1;  // np.pad(mode='edge') on the bottom / right
+    const unsigned char* ip = img + ((long long)ys * w0 + xs) * 3;
+    const unsigned char* mp = msk + ((long long)ys * w0 + xs) * mc;
+    // PIL "L" from RGB (ITU-R 601-2, fixed point); a single-channel mask is its own L
+    const unsigned l8 = mc == 1 ? mp[0] : ((unsigned)mp[0] * 19595u + (unsigned)mp[1] * 38470u + (unsigned)mp[2] * 7471u + 0x8000u) >> 16;
+    const float m = ((float)l8 / 255.0f) < 0.5f ? 0.f : 1.f;
+    float px[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) px[c] = (float)ip[c] / 127.5f - 1.0f;
+    for (int s = 0; s < n; ++s) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (image_out) image_out[((long long)s * 3 + c) * hw + i] = px[c];
+        if (masked_out) masked_out[((long long)s * 3 + c) * hw + i] = m < 0.5f ? px[c] : px[c] * 0.0f;  // x * False keeps the sign of zero
+      }
+      if (mask_out) mask_out[(long long)s * hw + i] = m;
+      if (mask_lat && (y & 7) == 0 && (x & 7) == 0) mask_lat[(long long)s * mask_lat_stride + (long long)(y >> 3) * (W >> 3) + (x >> 3)] = m;
+    }
+  }
+}
+
+extern "C" int sdmi_inpaint_prepare(const void* image_hwc_u8, const void* mask_u8, int h0, int w0, int mask_channels, int h, int w,
+                                    int num_samples, float* image, float* mask, float* masked_image, float* mask_latent,
+                                    int64_t mask_latent_stride, void* stream) {
+  SDMI_REQUIRE(image_hwc_u8 && mask_u8, "inpaint_prepare: null input");
+  SDMI_REQUIRE(h0 > 0 && w0 > 0 && h >= h0 && w >= w0 && num_samples > 0, "inpaint_prepare: bad sizes");
+  SDMI_REQUIRE(mask_channels == 1 || mask_channels == 3, "inpaint_prepare: mask has 1 (L) or 3 (RGB) channels");
+  SDMI_REQUIRE(!mask_latent || (h % 8 == 0 && w % 8 == 0), "inpaint_prepare: the latent mask needs h, w multiples of 8");
+  const long long hw = (long long)h * w;
+  const int blocks = (int)((hw + 255) / 256 < 4096 ? (hw + 255) / 256 : 4096);
+  hipLaunchKernelGGL(inpaint_prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)image_hwc_u8,
+                     (const unsigned char*)mask_u8, h0, w0, mask_channels, h, w, num_samples, image, mask, masked_image, mask_latent,
+                     (long long)mask_latent_stride);
+  return sdmi_check_launch("inpaint_prepare");
+}
+
+// DiagonalGaussianDistribution.sample() times the latent scale factor (AutoencoderKL.py:8-21, LatentDiffusionInpainting.py:289-291):
+// out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise), written into 4 channels of a (n, C, h, w) tensor
+// (the c_concat buffer, channels 1..4).
+__global__ __launch_bounds__(256) void posterior_sample_kernel(const float* __restrict__ moments, const float* __restrict__ noise,
+                                                               float scale, float* __restrict__ out, long long out_stride, int n,
+                                                               int hw) {
+  const long long total = (long long)n * 4 * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int s = (int)(i / (4ll * hw));
+    const long long r = i - (long long)s * 4 * hw;  // channel * hw + pixel
+    const float mean = moments[(long long)s * 8 * hw + r];
+    const float logvar = fminf(fmaxf(moments[(long long)s * 8 * hw + 4ll * hw + r], -30.0f), 20.0f);
+    out[(long long)s * out_stride + r] = scale * (mean + expf(0.5f * logvar) * noise[i]);
+  }
+}
+
+extern "C" int sdmi_posterior_sample(const float* moments, const float* noise, float scale, float* out, int64_t out_sample_stride,
+                                     int n, int hw, void* stream) {
+  SDMI_REQUIRE(moments && noise && out, "posterior_sample: null pointer");
+  SDMI_REQUIRE(n > 0 && hw > 0 && out_sample_stride >= 4ll * hw, "posterior_sample: bad sizes");
+  const long long total = (long long)n * 4 * hw;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(posterior_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, moments, noise, scale, out,
+                     (long long)out_sample_stride, n, hw);
+  return sdmi_check_launch("posterior_sample");
+}

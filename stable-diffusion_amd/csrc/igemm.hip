@@ -1152,7 +1152,10 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   {
     static int force = -2;
     if (force == -2) { const char* e = getenv("SDMI_NMAJOR"); force = e ? atoi(e) : -1; }
-    p.nmajor = force >= 0 ? force : (p.N > p.M ? 1 : 0);
+    // bytes of the two operands: weights N x K against activations M x K (GEMM) or M x Cin (conv: K = 9 Cin, the window
+    // of a row tile is fetched once per tile)
+    const long long wpanel = (long long)p.N * p.K, apanel = (long long)p.M * (CONV && !sdmi_option("conv_nmajor_by_rows") ? p.K / 9 : p.K);
+    p.nmajor = force >= 0 ? force : (wpanel > apanel ? 1 : 0);
   }
   p.ticket = nullptr;
   // Opt-in (SDMI_SPLITK_INKERNEL=1): bit-identical to the reduce kernel, but measured SLOWER on the UNet step (10.9 ms
@@ -1194,7 +1197,8 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 64, true>), grid, dim3(256), wbytes64, st, p);
         else hipLaunchKernelGGL((conv_win_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);
       }
-      sdmi_note_kernel("conv_win_kernel<128, %d>%s", bn, (p.splits > 1 && !p.ticket) ? " + igemm_splitk_reduce_kernel" : "");
+      sdmi_note_kernel("conv_win_kernel<128, %d, %s>%s", bn, p.colstats ? "true" : "false",
+                       (p.splits > 1 && !p.ticket) ? " + igemm_splitk_reduce_kernel" : "");
       int rcw = sdmi_check_launch("conv3x3 (shared window)");
       if (rcw || p.splits < 2 || p.ticket) return rcw;
       long long items = (long long)batch * p.M * (p.npad / 4);

@@ -204,11 +204,8 @@ class Sampler(object):
         LatentDiffusionInpainting.py:77-79 and :279-293): image (b,3,H,W) fp32 in [-1,1], mask (b,1,H,W) in {0,1} ->
         c_concat (b,5,H/8,W/8) = [nearest-resized mask | 0.18215 * encode(image * (mask < 0.5)).sample(noise)].
         noise (b,4,H/8,W/8) is the posterior's N(0,1) draw (drawn here when None)."""
-        masked = image * (mask < 0.5)
-        h, w = image.shape[-2] // 8, image.shape[-1] // 8
-        mask_lat = torch.nn.functional.interpolate(mask.float(), size=(h, w))
-        masked_lat = SCALE_FACTOR * self.vae.encode(masked).sample(noise)
-        return torch.cat([mask_lat, masked_lat], dim=1)
+        from .inpaint import image_conditioning
+        return image_conditioning(self.vae, {"mask": mask.float(), "masked_image": image * (mask < 0.5)}, noise)
 
     @torch.no_grad()
     def decode_to_uint8(self, latent, use_graph=False):

@@ -376,3 +376,65 @@ def test_attention_dispatch_long_self_attention_uses_kv_split_kernel():
     s = torch.randn(1, 77, 128, device=dev).to(H)
     E.attention(a, E.Act(s, 1, 1, 77, 128), E.Act(s, 1, 1, 77, 128), 2, log2q=True)
     assert L.load().sdmi_last_kernel().decode() == "attn64_kernel"
+
+
+# ------------------------------------------------------------------ (f)2: pre-processing on the device
+@pytest.mark.gpu
+@pytest.mark.parametrize("mask_mode", ["rgb", "L"])
+def test_make_batch_sd_on_device_equals_reference_fixture(golden, mask_mode):
+    """sdmi_inpaint_prepare through the reference-named make_batch_sd: unpadded uint8 image / mask in, the reference's
+    padded fp32 batch out (g9: outputs of the reference's own pad_image + make_batch_sd), bit for bit; the latent mask
+    lands in channel 0 of a c_concat buffer."""
+    from PIL import Image
+    from stable_diffusion_amd.inpaint import make_batch_sd
+    g = golden("g9_preprocess")
+    dev = torch.device("cuda", 0)
+    img, msk = g["image_u8"], g["mask_u8"]
+    want = {k: torch.from_numpy(g[k]) for k in ("image", "mask", "masked_image", "mask_latent")}
+    if mask_mode == "L":          # a single-channel mask is its own L: compare against the host definition instead
+        msk = np.array(Image.fromarray(msk).convert("L"))
+        b = O.make_batch_sd(O.pad_image(Image.fromarray(img)), O.pad_image(Image.fromarray(np.repeat(msk[:, :, None], 3, 2))), "p")
+        want.update(mask=b["mask"], masked_image=b["masked_image"],
+                    mask_latent=torch.nn.functional.interpolate(b["mask"], size=(16, 24)))
+    cc = torch.full((2, 5, 16, 24), -7.0, device=dev)
+    out = make_batch_sd(Image.fromarray(img), Image.fromarray(msk) if mask_mode == "rgb" else msk, "p", num_samples=2,
+                        device=dev, with_latent_mask=cc)
+    assert out["txt"] == ["p", "p"]
+    for k in ("image", "mask", "masked_image"):
+        got = out[k].cpu()
+        assert got.shape[0] == 2 and torch.equal(got[0], got[1])
+        assert torch.equal(got[:1], want[k]), k
+        # signed zeros of x * False included
+        assert torch.equal(got[:1].view(torch.int32), want[k].view(torch.int32)), k + " (bits)"
+    assert torch.equal(cc[:1, 0].cpu(), want["mask_latent"][:, 0]) and bool((cc[:, 1:] == -7.0).all())
+    # already padded input, no latent mask
+    out2 = make_batch_sd(g["padded_image_u8"], g["padded_mask_u8"], "p", device=dev, pad=False)
+    assert torch.equal(out2["masked_image"].cpu(), torch.from_numpy(g["masked_image"]))
+
+
+@pytest.mark.gpu
+def test_image_conditioning_from_uint8_vs_oracle(golden, nets):
+    """uint8 image + mask -> c_concat entirely on the device (sdmi_inpaint_prepare, encoder, sdmi_posterior_sample)
+    against the oracle's restatement of inpaint()'s c_cat loop with the same posterior noise."""
+    from PIL import Image
+    from stable_diffusion_amd.inpaint import make_batch_sd, image_conditioning
+    unet, vae, _, sd_v = nets
+    g = golden("g9_preprocess")
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(5)
+    noise = torch.from_numpy(rs.randn(1, 4, 16, 24).astype(np.float32))
+    cc = torch.empty((1, 5, 16, 24), device=dev)
+    batch = make_batch_sd(Image.fromarray(g["image_u8"]), Image.fromarray(g["mask_u8"]), "p", device=dev, with_latent_mask=cc)
+    out = image_conditioning(vae, batch, noise.to(dev), c_concat=cc).cpu()
+    ob = O.make_batch_sd(O.pad_image(Image.fromarray(g["image_u8"])), O.pad_image(Image.fromarray(g["mask_u8"])), "p")
+    want = O.image_conditioning(sd_v, ob, noise)
+    assert torch.equal(out[:, :1], want[:, :1])
+    e = rel_err(out[:, 1:].numpy(), want[:, 1:].numpy())
+    assert e[0] < 5e-3 * _tol() and e[1] < 3e-3 * _tol(), e
+    # the sample kernel alone: exact up to expf (<= 2 ulp of the std factor)
+    mom = torch.from_numpy(rs.randn(2, 8, 6, 5).astype(np.float32) * 4).to(dev)
+    nz = torch.from_numpy(rs.randn(2, 4, 6, 5).astype(np.float32)).to(dev)
+    buf = torch.zeros((2, 5, 6, 5), device=dev)
+    L.call("sdmi_posterior_sample", mom.data_ptr(), nz.data_ptr(), 0.18215, buf.data_ptr() + 4 * 30, 5 * 30, 2, 30, E._stream())
+    ref = 0.18215 * O.gaussian_sample(mom.cpu(), nz.cpu())
+    assert bool((buf[:, 0] == 0).all()) and rel_err(buf[:, 1:].cpu().numpy(), ref.numpy())[0] < 1e-6

@@ -115,3 +115,21 @@ def test_cfg_ddim_numpy_restatement_equals_torch_restatement():
         a, a0 = O.cfg_ddim_update(*args)
         b, b0 = O.cfg_ddim_update_np(*args)
         assert np.abs(a.numpy() - b).max() <= 1e-6 * np.abs(b).max() and np.abs(a0.numpy() - b0).max() <= 1e-6 * np.abs(b0).max()
+
+
+def test_preprocess_restatement_equals_reference_fixture(golden):
+    """G9: pad_image / make_batch_sd / the mask branch of the c_cat loop, outputs of the reference's own functions
+    (oracle/make_golden.py compiles them from its source) against the oracle's restatement: identical."""
+    from PIL import Image
+    g = golden("g9_preprocess")
+    pim, pmk = O.pad_image(Image.fromarray(g["image_u8"])), O.pad_image(Image.fromarray(g["mask_u8"]))
+    assert np.array_equal(np.array(pim), g["padded_image_u8"]) and np.array_equal(np.array(pmk), g["padded_mask_u8"])
+    b = O.make_batch_sd(pim, pmk, "p", num_samples=int(g["num_samples"]))
+    for k in ("image", "mask", "masked_image"):
+        assert b[k].shape[0] == 2 and np.array_equal(b[k][0].numpy(), g[k][0]) and torch.equal(b[k][0], b[k][1]), k
+    ml = torch.nn.functional.interpolate(b["mask"], size=(b["mask"].shape[2] // 8, b["mask"].shape[3] // 8))
+    assert np.array_equal(ml[:1].numpy(), g["mask_latent"])
+    # host-side helpers of the product mirror the same padding rule
+    from stable_diffusion_amd.inpaint import padded_size, pad_image
+    assert padded_size(150, 97) == (192, 128) and padded_size(64, 64) == (128, 128) and padded_size(768, 768) == (768, 768)
+    assert np.array_equal(np.array(pad_image(Image.fromarray(g["image_u8"]))), g["padded_image_u8"])
