@@ -215,6 +215,15 @@ int sdmi_attention_log2q(const void* q, int ldq, int64_t sq, const void* k, int 
                          int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv,
                          void* stream);
 
+/* ---- fused flash attention, ONE head of dim 512: the VAE mid block's attention (layers/SpatialTransformer.py:132-161,
+ *      xformers.ops.memory_efficient_attention on (B, HW, 512)) without an N x N score buffer.  q/k/v/o are h16 token-major
+ *      (B, n, >= 512) views with row strides ld* and per-batch element strides s*; o = softmax(q k^T * scale) v. */
+int sdmi_attention_d512(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v, int ldv,
+                        int64_t sv, void* o, int ldo, int64_t so, int batch, int n, float scale, void* stream);
+/*      Same for q that already carries scale * log2(e) (folded into the q projection's weight and bias). */
+int sdmi_attention_d512_log2q(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
+                              int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int n, void* stream);
+
 /* ---- row softmax (VAE single-head d=512 attention, layers/SpatialTransformer.py:151, runs as
  *      score GEMM -> this -> value GEMM).  x fp32 [rows][ldx] -> y bf16 [rows][ldy], y = softmax(x*scale). */
 int sdmi_softmax_rows(const float* x, int ldx, void* y, int ldy, int rows, int cols, float scale, void* stream);

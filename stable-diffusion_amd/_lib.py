@@ -63,6 +63,8 @@ PROTOTYPES = {
     "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),
     "sdmi_inpaint_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sdmi_posterior_sample": (_i, [_vp, _vp, _f, _vp, _i64, _i, _i, _vp]),
+    "sdmi_attention_d512": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _f, _vp]),
+    "sdmi_attention_d512_log2q": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _vp]),
     "sdmi_attention_log2q": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "sdmi_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "sdmi_cfg_ddim_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -147,7 +149,7 @@ def call(name, *args):
                 TIMER.records.append((name, TIMER.work_fn(name, args), e0, mid))
                 TIMER.records.append((kern[1], (0.0, 0.0), mid, e1))
                 e0 = None
-        elif name in ("sdmi_attention", "sdmi_attention_log2q"):
+        elif name.startswith("sdmi_attention"):
             name = lib.sdmi_last_kernel().decode() or "attn64_kernel"
         if e0 is not None:
             TIMER.records.append((name, TIMER.work_fn(name, args), e0, e1))

@@ -152,6 +152,15 @@ class MemoryEfficientAttnBlock(nn.Module):
     def run(self, a, out=None):
         c = self.in_channels
         xn = E.groupnorm(a, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
+        if c == 512 or c == 64:
+            # flash path: one fused q|k|v projection with the softmax scale * log2(e) folded into q's weight and bias, then
+            # the single-head kernel (d = 512: sdmi_attention_d512; d = 64: the UNet's kernel with one head)
+            sc = (float(c) ** -0.5 * 1.4426950408889634, None, None)
+            ws, bs = (self.q.weight, self.k.weight, self.v.weight), (self.q.bias, self.k.bias, self.v.bias)
+            qkv = E.gemm(xn, E.packed_linear(ws, scales=sc), 3 * c, bias=E.stacked_f32(bs, scales=sc))
+            q, k, v = qkv.cols(0, c), qkv.cols(c, c), qkv.cols(2 * c, c)
+            o = E.attention_d512(q, k, v, log2q=True) if c == 512 else E.attention(q, k, v, 1, log2q=True)
+            return E.gemm(o, E.packed_linear((self.proj_out.weight,)), c, bias=self.proj_out.bias, residual=a, out=out)
         qk = E.gemm(xn, E.packed_linear((self.q.weight, self.k.weight)), 2 * c, bias=E.stacked_f32((self.q.bias, self.k.bias)))
         o = E.vae_attention_core(qk, xn, E.packed_linear((self.v.weight,)), self.v.bias, c)
         return E.gemm(o, E.packed_linear((self.proj_out.weight,)), c, bias=self.proj_out.bias, residual=a, out=out)

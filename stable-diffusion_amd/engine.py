@@ -171,10 +171,12 @@ def packed_linear(weights, geglu=False, scales=None):
     return PACK.get(weights, ("lg" if geglu else "l") + repr(scales if any(scales) else ""), build)
 
 
-def stacked_f32(params):
-    """Concatenate 1-D fp32 parameters (stacked biases of fused projections)."""
+def stacked_f32(params, scales=None):
+    """Concatenate 1-D fp32 parameters (stacked biases of fused projections); scales: one constant per parameter."""
     params = tuple(params)
-    return PACK.get(params, "cat", lambda: torch.cat([_f32c(p, "bias") for p in params]).contiguous())
+    scales = tuple(scales) if scales is not None else (None,) * len(params)
+    return PACK.get(params, "cat" + repr(scales if any(scales) else ""),
+                    lambda: torch.cat([_scaled(_f32c(p, "bias"), sc) for p, sc in zip(params, scales)]).contiguous())
 
 
 # --------------------------------------------------------------------------- split-K workspace
@@ -470,6 +472,23 @@ def timestep_embedding(t, dim, max_period=10000):
         raise L.SdmiError("timestep_embedding: odd dim unsupported")
     L.call("sdmi_timestep_embedding", t.data_ptr(), _FREQS[key].data_ptr(), out.data_ptr(), t.shape[0], half, _stream())
     return out
+
+
+def attention_d512(q, k, v, out=None, log2q=False):
+    """softmax(q k^T / sqrt(512)) v, one head of dim 512, flash-style (no N x N buffer): q/k/v are column views of token
+    buffers.  log2q: q already carries 512^-0.5 * log2(e)."""
+    if (q.c, k.c, v.c) != (512, 512, 512) or (k.n, v.n, v.hw) != (q.n, q.n, k.hw):
+        raise L.SdmiError("attention_d512: q (%d,%d,%d) / k (%d,%d,%d) / v (%d,%d,%d)" % (q.n, q.hw, q.c, k.n, k.hw, k.c, v.n, v.hw, v.c))
+    o = out if out is not None else new_act(q.n, q.h, q.w, 512, q.device)
+    _check_out(o, q.n, q.h, q.w, 512, "attention_d512")
+    if q.hw != k.hw:
+        raise L.SdmiError("attention_d512: self-attention only (%d queries, %d keys)" % (q.hw, k.hw))
+    args = (q.ptr, q.ld, q.hw * q.ld, k.ptr, k.ld, k.hw * k.ld, v.ptr, v.ld, v.hw * v.ld, o.ptr, o.ld, o.hw * o.ld, q.n, q.hw)
+    if log2q:
+        L.call("sdmi_attention_d512_log2q", *(args + (_stream(),)))
+    else:
+        L.call("sdmi_attention_d512", *(args + (512.0 ** -0.5, _stream())))
+    return o
 
 
 def vae_attention_core(qk, xn, wv_packed, bv, c):

@@ -438,3 +438,72 @@ def test_image_conditioning_from_uint8_vs_oracle(golden, nets):
     L.call("sdmi_posterior_sample", mom.data_ptr(), nz.data_ptr(), 0.18215, buf.data_ptr() + 4 * 30, 5 * 30, 2, 30, E._stream())
     ref = 0.18215 * O.gaussian_sample(mom.cpu(), nz.cpu())
     assert bool((buf[:, 0] == 0).all()) and rel_err(buf[:, 1:].cpu().numpy(), ref.numpy())[0] < 1e-6
+
+
+# ------------------------------------------------------------------ VAE mid-block attention: flash, one head of dim 512
+def _attn512_ref(q, k, v):
+    return torch.softmax(q.double() @ k.double().transpose(-1, -2) * 512.0 ** -0.5, dim=-1) @ v.double()
+
+
+@pytest.mark.gpu
+def test_attention_d512_known_answer(golden):
+    """g5's (1, 130, 512) fp64 known-answer vector through sdmi_attention_d512 (ragged: 130 = 4 tiles + 2 keys)."""
+    g = golden("g5_attention")
+    H = E.act_dtype()
+    mk = lambda a: E.Act(torch.from_numpy(a).to(DEV).to(H).contiguous(), 1, 1, a.shape[1], 512)
+    o = E.attention_d512(mk(g["vae_q"]), mk(g["vae_k"]), mk(g["vae_v"])).buf.float().cpu()
+    e = rel_err(o.numpy(), g["vae_o"])
+    assert e[0] < 1.5e-3 * _tol() and e[1] < 6e-4 * _tol(), e
+    assert L.load().sdmi_last_kernel().decode() == "attn512_kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,kind", [(1, 33, "plain"), (2, 64, "plain"), (1, 1000, "plain"), (2, 257, "wide"), (1, 576, "late_spike")])
+def test_attention_d512_vs_fp64(b, n, kind):
+    """Both entry points against the fp64 definition on the 16-bit inputs: ragged tails, a batch, logits of +-150 and a
+    late key that moves the running maximum; strided (fused q|k|v buffer) views as the VAE block passes them."""
+    g = torch.Generator(device="cpu").manual_seed(n)
+    q, k, v = (torch.randn(b, n, 512, generator=g) for _ in range(3))
+    if kind == "wide":
+        q *= 2.5
+        k *= 2.5
+    if kind == "late_spike":
+        k[:, 500] = q[:, 7] * 2.0
+    H = E.act_dtype()
+    sc = 512.0 ** -0.5 * 1.4426950408889634
+    qkv = torch.cat([q, k, v], dim=2).to(DEV).to(H).contiguous()              # one (b, n, 1536) buffer, views by column
+    A = E.Act(qkv, b, 1, n, 1536)
+    want = _attn512_ref(qkv[..., :512].cpu(), qkv[..., 512:1024].cpu(), qkv[..., 1024:].cpu())
+    got = E.attention_d512(A.cols(0, 512), A.cols(512, 512), A.cols(1024, 512)).buf.double().cpu()
+    l2 = lambda a, b_: float((a - b_).norm() / b_.norm())
+    assert torch.isfinite(got).all() and l2(got, want) < (6e-4 if kind != "wide" else 2e-3) * _tol(), l2(got, want)
+    ql = (q * sc).to(DEV).to(H)
+    qkv2 = torch.cat([ql, qkv[..., 512:]], dim=2).contiguous()
+    A2 = E.Act(qkv2, b, 1, n, 1536)
+    want2 = _attn512_ref(ql.double().cpu() / sc, qkv[..., 512:1024].cpu(), qkv[..., 1024:].cpu())
+    got2 = E.attention_d512(A2.cols(0, 512), A2.cols(512, 512), A2.cols(1024, 512), log2q=True).buf.double().cpu()
+    assert l2(got2, want2) < 6e-4 * _tol(), l2(got2, want2)
+
+
+@pytest.mark.gpu
+def test_vae_attn_block_allocates_no_score_buffer(nets):
+    """The VAE mid block at 96 x 96 (9216 tokens): the flash kernel runs, peak memory of the call stays O(N d) (the N x N
+    fp32 scores alone would be 340 MB), and the result matches the oracle's block on the same input."""
+    unet, vae, _, sd_v = nets
+    blk = vae.decoder.mid.attn_1
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.randn(1, 512, 96, 96).astype(np.float32))
+    a = E.from_nchw(x.to(DEV))
+    blk.run(a)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    y = blk.run(a)
+    torch.cuda.synchronize()
+    assert L.load().sdmi_last_kernel().decode().startswith("igemm_kernel")           # proj_out ran last ...
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 80 << 20, "peak %d MB" % (peak >> 20)                              # x_n 9.4 + qkv 28 + o 9.4 + y 9.4 MB
+    sd = {k[len("decoder.mid.attn_1."):]: v for k, v in sd_v.items() if k.startswith("decoder.mid.attn_1.")}
+    want = O.vae_attn_block({"b." + k: v for k, v in sd.items()}, "b", x)
+    e = rel_err(E.to_nchw(y).cpu().numpy(), want.numpy())
+    assert e[0] < 5e-3 * _tol() and e[1] < 1.5e-3 * _tol(), e
