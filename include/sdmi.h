@@ -224,6 +224,20 @@ int sdmi_attention_d512(const void* q, int ldq, int64_t sq, const void* k, int l
 int sdmi_attention_d512_log2q(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
                               int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int n, void* stream);
 
+/* ---- causal multi-head attention (head_dim 64) for short sequences: the text encoder's self-attention with open_clip's
+ *      additive causal mask (LatentDiffusionInpainting.py:238-241, r(x, attn_mask=...)).  Same views as sdmi_attention;
+ *      query i attends to keys 0..i.  Runs once per prompt (77 tokens): a plain fp32 kernel, not an MFMA one. */
+int sdmi_attention_causal(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v, int ldv,
+                          int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int n, float scale, void* stream);
+
+/* ---- text encoder pieces (LatentDiffusionInpainting.py:232-245, get_conditional):
+ *      sdmi_embed_tokens: out[row] = h16(table[tokens[row]] + pos[row % seq_len]) (token_embedding + positional_embedding,
+ *      :234-235); tokens int64 [rows], table fp32 [vocab][width], pos fp32 [seq_len][width], out h16 [rows][ldo].
+ *      sdmi_gelu_rows: exact (erf) GELU in place on h16 [rows][ldx] (the MLP activation of a resblock, :241). */
+int sdmi_embed_tokens(const int64_t* tokens, const float* table, const float* pos, void* out, int rows, int seq_len, int width,
+                      int vocab, int ldo, void* stream);
+int sdmi_gelu_rows(void* x, int ldx, int rows, int cols, void* stream);
+
 /* ---- row softmax (VAE single-head d=512 attention, layers/SpatialTransformer.py:151, runs as
  *      score GEMM -> this -> value GEMM).  x fp32 [rows][ldx] -> y bf16 [rows][ldy], y = softmax(x*scale). */
 int sdmi_softmax_rows(const float* x, int ldx, void* y, int ldy, int rows, int cols, float scale, void* stream);

@@ -284,6 +284,34 @@ def image_conditioning(sd_vae, batch, noise, scale_factor=0.18215):
     return torch.cat([mask_lat, lat], dim=1)
 
 
+# --------------------------------------------------------------------------- text encoder
+def clip_text_encode(sd, tokens, heads=16):
+    """LatentDiffusionInpainting.get_conditional (:232-245) on token ids, with open_clip's text tower restated from its
+    published definition (mlfoundations/open_clip `CLIP.encode_text` / `ResidualAttentionBlock`; the package is a
+    dependency the reference does not pin and that is absent here, so this restatement is PARITY UNPINNED):
+        x = token_embedding[tokens] + positional_embedding
+        for every block but the last:  x = x + MHA(ln_1(x), causal -inf mask);  x = x + c_proj(GELU(c_fc(ln_2(x))))
+        x = ln_final(x)
+    MHA is nn.MultiheadAttention's arithmetic: in_proj -> (q, k, v), heads of width/heads, softmax(q k^T / sqrt(d) + mask) v,
+    out_proj.  sd: open_clip's state_dict names."""
+    x = sd["token_embedding.weight"][tokens] + sd["positional_embedding"]
+    b, t, w = x.shape
+    mask = torch.full((t, t), float("-inf")).triu_(1)
+    n = _count(sd, "transformer.resblocks")
+    for i in range(n - 1):
+        p = "transformer.resblocks.%d" % i
+        h = F.layer_norm(x, (w,), sd[p + ".ln_1.weight"], sd[p + ".ln_1.bias"], 1e-5)
+        qkv = F.linear(h, sd[p + ".attn.in_proj_weight"], sd[p + ".attn.in_proj_bias"])
+        q, k, v = (z.reshape(b, t, heads, w // heads).permute(0, 2, 1, 3) for z in qkv.chunk(3, dim=-1))
+        a = torch.softmax(q @ k.transpose(-1, -2) * (w // heads) ** -0.5 + mask, dim=-1) @ v
+        a = a.permute(0, 2, 1, 3).reshape(b, t, w)
+        x = x + F.linear(a, sd[p + ".attn.out_proj.weight"], sd[p + ".attn.out_proj.bias"])
+        h = F.layer_norm(x, (w,), sd[p + ".ln_2.weight"], sd[p + ".ln_2.bias"], 1e-5)
+        h = F.gelu(F.linear(h, sd[p + ".mlp.c_fc.weight"], sd[p + ".mlp.c_fc.bias"]))
+        x = x + F.linear(h, sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"])
+    return F.layer_norm(x, (w,), sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)
+
+
 # --------------------------------------------------------------------------- sampler
 def ddim_schedule(num_ddim_timesteps, eta=1.0, num_train=1000, linear_start=1e-4, linear_end=2e-2):
     """Timesteps and per-step coefficients exactly as LatentDiffusionInpainting.py:125-135, :150-159

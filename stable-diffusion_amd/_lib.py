@@ -65,6 +65,9 @@ PROTOTYPES = {
     "sdmi_posterior_sample": (_i, [_vp, _vp, _f, _vp, _i64, _i, _i, _vp]),
     "sdmi_attention_d512": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _f, _vp]),
     "sdmi_attention_d512_log2q": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _vp]),
+    "sdmi_attention_causal": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _f, _vp]),
+    "sdmi_embed_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sdmi_gelu_rows": (_i, [_vp, _i, _i, _i, _vp]),
     "sdmi_attention_log2q": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "sdmi_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "sdmi_cfg_ddim_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -533,3 +533,49 @@ extern "C" int sdmi_attention_log2q(const void* q, int ldq, int64_t sq, const vo
                                     int nkv, void* stream) {
   return attention_launch(q, ldq, sq, k, ldk, sk, v, ldv, sv, o, ldo, so, batch, heads, nq, nkv, 1.0f, true, stream);
 }
+
+// ------------------------------------------------------------------------------------------ causal attention, short sequences
+// The text encoder's self-attention (77 tokens, 16 heads of 64, additive causal mask: open_clip build_attention_mask,
+// used at LatentDiffusionInpainting.py:241): runs once per prompt on a few thousand rows, so it is written for clarity,
+// not for the matrix cores: one wave per (batch, head, query row), the head dimension on the lanes, fp32 online softmax
+// over the keys 0 .. row.
+__global__ __launch_bounds__(256) void attn_causal_rows_kernel(const AttnParams p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long wid = (long long)blockIdx.x * 4 + wv;
+  const long long total = (long long)p.nq * p.heads * p.nqt;  // nqt carries the batch here
+  if (wid >= total) return;
+  const int row = (int)(wid % p.nq);
+  const int head = (int)((wid / p.nq) % p.heads), bz = (int)(wid / ((long long)p.nq * p.heads));
+  const u16* Q = p.q + (long long)bz * p.sq + head * 64;
+  const u16* K = p.k + (long long)bz * p.sk + head * 64;
+  const u16* V = p.v + (long long)bz * p.sv + head * 64;
+  const float q = h2f(Q[(long long)row * p.ldq + lane]) * p.scale_log2;
+  float m = -1e30f, l = 0.f, acc = 0.f;
+  for (int j = 0; j <= row && j < p.nkv; ++j) {
+    const float s = wave_sum(q * h2f(K[(long long)j * p.ldk + lane]));
+    const float mnew = fmaxf(m, s);
+    const float a = __builtin_amdgcn_exp2f(m - mnew), e = __builtin_amdgcn_exp2f(s - mnew);
+    l = l * a + e;
+    acc = acc * a + e * h2f(V[(long long)j * p.ldv + lane]);
+    m = mnew;
+  }
+  p.o[(long long)bz * p.so + (long long)row * p.ldo + head * 64 + lane] = f2h(acc / l);
+}
+
+extern "C" int sdmi_attention_causal(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
+                                     int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int n,
+                                     float scale, void* stream) {
+  SDMI_REQUIRE(q && k && v && o, "attention_causal: null pointer");
+  SDMI_REQUIRE(batch > 0 && heads > 0 && n > 0 && n <= 4096, "attention_causal: bad shape (sequences up to 4096 tokens)");
+  SDMI_REQUIRE(ldq >= heads * 64 && ldk >= heads * 64 && ldv >= heads * 64 && ldo >= heads * 64, "attention_causal: row stride < heads*64");
+  SDMI_REQUIRE(scale > 0.f, "attention_causal: scale must be positive");
+  AttnParams p;
+  p.q = (const u16*)q; p.k = (const u16*)k; p.v = (const u16*)v; p.o = (u16*)o;
+  p.sq = sq; p.sk = sk; p.sv = sv; p.so = so; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.nq = n; p.nkv = n; p.heads = heads; p.nqt = batch; p.scale_log2 = scale * 1.44269504088896340736f;
+  const long long waves = (long long)n * heads * batch;
+  SDMI_REQUIRE((waves + 3) / 4 < (1ll << 31), "attention_causal: grid too large");
+  hipLaunchKernelGGL(attn_causal_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  sdmi_note_kernel("attn_causal_rows_kernel");
+  return sdmi_check_launch("attention_causal");
+}

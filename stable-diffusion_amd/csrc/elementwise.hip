@@ -339,3 +339,55 @@ extern "C" int sdmi_posterior_sample(const float* moments, const float* noise, f
                      (long long)out_sample_stride, n, hw);
   return sdmi_check_launch("posterior_sample");
 }
+
+// ------------------------------------------------------------------------------------------ text encoder pieces
+// token_embedding(tokens) + positional_embedding (LatentDiffusionInpainting.py:234-235; open_clip CLIP.encode_text):
+// out[b*T + t][:] = h16(table[tokens[b][t]][:] + pos[t][:]).  One block per token row.
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ table,
+                                                           const float* __restrict__ pos, u16* __restrict__ out, int T, int width,
+                                                           int vocab, int ldo) {
+  const int row = blockIdx.x, tpos = row % T;
+  long long tok = tokens[row];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // host checks the range; never read outside the table
+  const float* src = table + tok * (long long)width;
+  const float* ps = pos + (long long)tpos * width;
+  for (int c = threadIdx.x * 4; c < width; c += 1024) {
+    const float4 a = *(const float4*)(src + c), b = *(const float4*)(ps + c);
+    *(uint2*)(out + (long long)row * ldo + c) = make_uint2(pack2h(a.x + b.x, a.y + b.y), pack2h(a.z + b.z, a.w + b.w));
+  }
+}
+
+extern "C" int sdmi_embed_tokens(const int64_t* tokens, const float* table, const float* pos, void* out, int rows, int seq_len,
+                                 int width, int vocab, int ldo, void* stream) {
+  SDMI_REQUIRE(tokens && table && pos && out, "embed_tokens: null pointer");
+  SDMI_REQUIRE(rows > 0 && seq_len > 0 && rows % seq_len == 0 && width > 0 && width % 4 == 0 && vocab > 0 && ldo >= width && ldo % 4 == 0,
+               "embed_tokens: bad sizes (rows=%d seq_len=%d width=%d)", rows, seq_len, width);
+  SDMI_REQUIRE((((uintptr_t)table | (uintptr_t)pos) & 15) == 0 && ((uintptr_t)out & 7) == 0, "embed_tokens: alignment");
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, tokens, table, pos, (u16*)out, seq_len, width, vocab, ldo);
+  return sdmi_check_launch("embed_tokens");
+}
+
+// exact (erf) GELU in place on an h16 matrix: the activation between c_fc and c_proj of the text encoder's MLP
+// (open_clip ResidualAttentionBlock.mlp = Linear -> nn.GELU() -> Linear).
+__global__ __launch_bounds__(256) void gelu_rows_kernel(u16* __restrict__ x, int ldx, int rows, int cols) {
+  const int cc = cols >> 3;
+  const long long total = (long long)rows * cc;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / cc), c = (int)(i - (long long)r * cc);
+    uint4* ptr = (uint4*)(x + (long long)r * ldx + c * 8);
+    float f[8];
+    unpack8(*ptr, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.5f * f[e] * (1.0f + erff(f[e] * 0.70710678118654752f));
+    *ptr = pack8(f);
+  }
+}
+
+extern "C" int sdmi_gelu_rows(void* x, int ldx, int rows, int cols, void* stream) {
+  SDMI_REQUIRE(x && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldx >= cols, "gelu_rows: cols and ldx must be multiples of 8");
+  SDMI_REQUIRE(((uintptr_t)x & 15) == 0, "gelu_rows: alignment");
+  const long long total = (long long)rows * (cols / 8);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(gelu_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (u16*)x, ldx, rows, cols);
+  return sdmi_check_launch("gelu_rows");
+}

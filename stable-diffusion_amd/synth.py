@@ -44,7 +44,7 @@ def fill_state_dict(sd, seed=0, fast=False):
                 a = np.float32(1.0) + np.float32(0.1) * randn(shape)
             else:
                 a = np.float32(0.05) * randn(shape)
-            v.copy_(torch.from_numpy(a.astype(np.float32)).to(v.device))
+            v.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape)).to(v.device))
     return sd
 
 

@@ -507,3 +507,54 @@ def test_vae_attn_block_allocates_no_score_buffer(nets):
     want = O.vae_attn_block({"b." + k: v for k, v in sd.items()}, "b", x)
     e = rel_err(E.to_nchw(y).cpu().numpy(), want.numpy())
     assert e[0] < 5e-3 * _tol() and e[1] < 1.5e-3 * _tol(), e
+
+
+# ------------------------------------------------------------------ (f)4: text encoder
+@pytest.mark.gpu
+def test_clip_text_encoder_vs_oracle():
+    """ClipTextEncoder.get_conditional at the ViT-H-14 text-tower shapes (24 blocks of width 1024, 23 run) against the
+    oracle's restatement, random-init weights, two prompts of random token ids.  Parity unpinned upstream (open_clip and
+    its weights are absent): this pins the HIP path to the restatement only.  Gate: rel-L2 3e-3 on the LayerNorm-ed
+    output (16-bit residual stream over 23 blocks; measured ~1e-3)."""
+    from stable_diffusion_amd.clip_text import ClipTextEncoder
+    m = ClipTextEncoder()
+    sd = {k: v.clone() for k, v in fill_state_dict(m.state_dict(), seed=6).items()}
+    m = m.to(DEV).eval()
+    rs = np.random.RandomState(8)
+    tokens = torch.from_numpy(rs.randint(0, 49408, size=(2, 77)))
+    got = m.get_conditional(tokens.to(DEV)).cpu()
+    assert got.shape == (2, 77, 1024) and got.dtype == torch.float32
+    want = O.clip_text_encode(sd, tokens)
+    e = rel_err(got.numpy(), want.numpy())
+    assert e[1] < 3e-3 * _tol() and e[0] < 2e-2 * _tol(), e
+    # causal: changing the tail of a prompt leaves the head's rows bit-identical
+    t2 = tokens.clone()
+    t2[:, 50:] = 7
+    got2 = m.get_conditional(t2.to(DEV)).cpu()
+    assert torch.equal(got2[:, :50], got[:, :50]) and not torch.equal(got2[:, 50:], got[:, 50:])
+    with pytest.raises(L.SdmiError):
+        m.get_conditional(torch.full((1, 77), 49408, dtype=torch.long))
+    # the result is what Unet.forward takes as `context`
+    assert got.is_contiguous()
+
+
+@pytest.mark.gpu
+def test_causal_attention_and_gelu_kernels():
+    dev = torch.device("cuda", 0)
+    H = E.act_dtype()
+    g = torch.Generator().manual_seed(1)
+    b, heads, n = 2, 3, 77
+    q, k, v = (torch.randn(b, n, heads * 64, generator=g).to(dev).to(H) for _ in range(3))
+    o = torch.empty_like(q)
+    ld = heads * 64
+    L.call("sdmi_attention_causal", q.data_ptr(), ld, n * ld, k.data_ptr(), ld, n * ld, v.data_ptr(), ld, n * ld, o.data_ptr(), ld,
+           n * ld, b, heads, n, 0.125, E._stream())
+    sp = lambda t: t.double().cpu().reshape(b, n, heads, 64).permute(0, 2, 1, 3)
+    mask = torch.full((n, n), float("-inf"), dtype=torch.float64).triu_(1)
+    want = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * 0.125 + mask, dim=-1) @ sp(v)).permute(0, 2, 1, 3).reshape(b, n, ld)
+    assert float((o.double().cpu() - want).norm() / want.norm()) < 4e-4 * _tol()
+    x = (torch.randn(50, 264, generator=g) * 3).to(dev).to(H)
+    ref = torch.nn.functional.gelu(x[:, :256].float()).to(H)
+    keep = x[:, 256:].clone()
+    L.call("sdmi_gelu_rows", x.data_ptr(), 264, 50, 256, E._stream())
+    assert torch.equal(x[:, 256:], keep) and float((x[:, :256].float() - ref.float()).abs().max()) < 4e-3 * _tol()

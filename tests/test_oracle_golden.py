@@ -133,3 +133,42 @@ def test_preprocess_restatement_equals_reference_fixture(golden):
     from stable_diffusion_amd.inpaint import padded_size, pad_image
     assert padded_size(150, 97) == (192, 128) and padded_size(64, 64) == (128, 128) and padded_size(768, 768) == (768, 768)
     assert np.array_equal(np.array(pad_image(Image.fromarray(g["image_u8"]))), g["padded_image_u8"])
+
+
+def test_clip_text_restatement_equals_torch_multihead_attention():
+    """The oracle's restatement of open_clip's text tower (parity unpinned: open_clip is absent) against the same blocks
+    built from torch.nn.MultiheadAttention in (L, N, D) layout with the additive causal mask - the module and call open_clip's
+    ResidualAttentionBlock uses - on a small width; plus causality: later tokens do not change earlier positions."""
+    from stable_diffusion_amd.clip_text import ClipTextEncoder
+    torch.manual_seed(0)
+    w, heads, layers, T_, vocab = 128, 2, 3, 77, 500
+    m = ClipTextEncoder(vocab_size=vocab, context_length=T_, width=w, heads=heads, layers=layers)
+    sd = {k: v.clone() for k, v in fill_state_dict(m.state_dict(), seed=4).items()}
+    rs = np.random.RandomState(2)
+    tokens = torch.from_numpy(rs.randint(0, vocab, size=(2, T_)))
+    got = O.clip_text_encode(sd, tokens, heads=heads)
+    x = (sd["token_embedding.weight"][tokens] + sd["positional_embedding"]).permute(1, 0, 2)       # NLD -> LND
+    mask = torch.full((T_, T_), float("-inf")).triu_(1)
+    for i in range(layers - 1):
+        p = "transformer.resblocks.%d." % i
+        mha = torch.nn.MultiheadAttention(w, heads)
+        mha.load_state_dict({"in_proj_weight": sd[p + "attn.in_proj_weight"], "in_proj_bias": sd[p + "attn.in_proj_bias"],
+                             "out_proj.weight": sd[p + "attn.out_proj.weight"], "out_proj.bias": sd[p + "attn.out_proj.bias"]})
+        ln = lambda t, q: torch.nn.functional.layer_norm(t, (w,), sd[p + q + ".weight"], sd[p + q + ".bias"], 1e-5)
+        h = ln(x, "ln_1")
+        x = x + mha(h, h, h, need_weights=False, attn_mask=mask)[0]
+        h = torch.nn.functional.linear(ln(x, "ln_2"), sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"])
+        x = x + torch.nn.functional.linear(torch.nn.functional.gelu(h), sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"])
+    want = torch.nn.functional.layer_norm(x.permute(1, 0, 2), (w,), sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)
+    assert float((got - want).abs().max()) < 2e-5
+    t2 = tokens.clone()
+    t2[:, 40:] = torch.from_numpy(rs.randint(0, vocab, size=(2, T_ - 40)))
+    got2 = O.clip_text_encode(sd, t2, heads=heads)
+    assert torch.equal(got2[:, :40], got[:, :40]) and not torch.equal(got2[:, 40:], got[:, 40:])
+    # open_clip's key set for the text tower (what the reference checkpoint's cond_stage_model.* entries are named)
+    keys = set(m.state_dict().keys())
+    for k in ("token_embedding.weight", "positional_embedding", "ln_final.weight", "text_projection", "logit_scale",
+              "transformer.resblocks.0.attn.in_proj_weight", "transformer.resblocks.2.mlp.c_proj.bias",
+              "transformer.resblocks.1.attn.out_proj.weight", "transformer.resblocks.0.ln_2.bias"):
+        assert k in keys, k
+    assert "attn_mask" not in keys
