@@ -8,7 +8,7 @@ attn.in_proj_weight / attn.in_proj_bias / attn.out_proj / ln_2 / mlp.c_fc / mlp.
 `logit_scale`), so the `cond_stage_model.*` entries of the reference's checkpoint remap (:257) load with
 load_state_dict().  open_clip itself (mlfoundations/open_clip, version not pinned by the reference) and its BPE vocabulary
 are not in this image: callers pass token ids (what `open_clip.tokenize` returns), and parity is against the oracle's
-restatement of the published block (oracle/sd_oracle.py: clip_text_encode) - parity unpinned, see DESIGN.md."""
+restatement of the published block (clip_text_encode in the test oracle) - parity unpinned, see DESIGN.md."""
 import torch
 from torch import nn
 
