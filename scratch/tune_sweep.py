@@ -1,6 +1,6 @@
 """(tile variant, split-K factor) sweep on the UNet's conv / GEMM shapes at 768x768, CFG batch 2; graph chains of 20 launches."""
 import sys, time, json, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import stable_diffusion_amd
 from stable_diffusion_amd import engine as E, _lib
 dev = "cuda"; H = E.act_dtype()
@@ -60,11 +60,12 @@ def gemm(m, n, k, geglu=False):
     fn = lambda: E.gemm(a, w, n, bias=b, residual=res, geglu=geglu, out=out)
     sweep("gemm %d x %d x %d%s" % (m, n, k, " geglu" if geglu else ""), fn, (k + 63) // 64, 2.0 * m * n * k)
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+NB = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 if which in ("all", "conv"):
     for a in [(96, 320, 320), (96, 640, 320), (96, 960, 320), (96, 640, 640, 1, True), (48, 320, 320, 2), (48, 320, 640), (48, 640, 640), (48, 1280, 640), (48, 1920, 640), (48, 960, 640),
               (48, 1280, 1280, 1, True), (24, 640, 640, 2), (24, 640, 1280), (24, 1280, 1280), (24, 2560, 1280), (24, 1920, 1280), (24, 1280, 1280, 1, True),
               (12, 1280, 1280, 2), (12, 1280, 1280), (12, 2560, 1280)]:
-        conv(*a)
+        conv(*a, **({} if len(a) > 5 else {'n': NB}))
 if which in ("all", "gemm"):
     for a in [(18432, 320, 320), (18432, 960, 320), (18432, 2560, 320, True), (18432, 320, 1280), (18432, 320, 640), (18432, 320, 960),
               (4608, 640, 640), (4608, 1920, 640), (4608, 5120, 640, True), (4608, 640, 2560), (4608, 640, 320), (4608, 640, 1280), (4608, 640, 1920), (4608, 640, 960),

@@ -45,7 +45,13 @@ extern "C" const char* sdmi_last_error(void) { return g_err; }
 #include <string.h>
 static struct { const char* name; int value; } g_options[] = {
     {"conv_nmajor_by_rows", 0}, // 1: conv tile order by N > M as in round 1 (0: by operand bytes, 9 N > M)
+    {"splitk_target", 0},       // > 0: blocks a split-K launch aims for per sample (default 512; round 1: 384)
+    {"splitk_max_tiles", 0},    // > 0: split K only when a sample has at most this many tiles (default 256; round 1: 128)
+    {"splitk_min_kt_conv", 0},  // > 0: K-tiles (of 64) a conv split keeps at least (default 16)
+    {"splitk_min_kt_gemm", 0},  // > 0: same for plain GEMMs (default 24; round 1: 32)
+    {"bm128_min", 0},           // > 0: 128-row tiles once they number at least this (default 128)
     {"gemm_small_m_tile", 1},   // 1: 64x64 tiles for K >= 2048 GEMMs with fewer than 1024 rows (0: 64x128 as in round 1)
+    {"attn_x2_min_nq", 0},      // > 0: query rows from which long self-attention takes the 64-rows-per-wave kernel (default 2048)
     {"attn_variant", 0},        // attention kernel variant (0 = default)
 };
 int sdmi_option(const char* name) {

@@ -980,17 +980,21 @@ static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags, boo
   static int target = -1;
   if (target < 0) {
     const char* e = getenv("SDMI_SPLITK_TARGET");
-    target = e ? atoi(e) : 384;
+    target = e ? atoi(e) : 512;
   }
   if (target <= 0) return 1;
   const int bn = ((n % 128 == 0) || (n > 512)) ? 128 : 64;
   const int bm = rows_per_sample >= 1024 ? 128 : 64;
   const long long tiles = (long long)((rows_per_sample + bm - 1) / bm) * ((n + bn - 1) / bn);
-  if (tiles > 128) return 1;
-  long long s = target / tiles;
-  // at least 1024 of K per split (plain GEMMs: 2048), below that the fp32 round trip costs more than it buys (sweep of
-  // the UNet's shapes, scratch/tune_sweep.py: K = 2560 GEMMs ran 25-35 % faster unsplit)
-  const int min_kt = conv ? 16 : 32;
+  const int opt_target = sdmi_option("splitk_target"), opt_max = sdmi_option("splitk_max_tiles");
+  if (tiles > (opt_max > 0 ? opt_max : 256)) return 1;
+  long long s = (opt_target > 0 ? opt_target : target) / tiles;
+  // at least 1024 of K per split (plain GEMMs: 1536), below that the fp32 round trip costs more than it buys (sweep of
+  // the UNet's shapes, scratch/tune_sweep.py: K = 2560 GEMMs ran 25-35 % faster unsplit).  Round 2, with the two CFG
+  // halves as concurrent batch-1 passes (scratch/ab_step.py, same-process A/B of the captured step): 512 blocks per
+  // sample instead of 384 and splitting up to 256 tiles instead of 128 -1.3 %, GEMM splits from K = 3072 -0.5 %.
+  const int opt_kt = sdmi_option(conv ? "splitk_min_kt_conv" : "splitk_min_kt_gemm");
+  const int min_kt = opt_kt > 0 ? opt_kt : (conv ? 16 : 24);
   if (s > nk / min_kt) s = nk / min_kt;
   if (s > 16) s = 16;
   return s < 2 ? 1 : (int)s;
@@ -1078,7 +1082,8 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   // the two CFG halves as concurrent batch-1 passes, so the other half of the chip is not idle (256 -> 128: +3.3 %
   // images/s at 768x768; SDMI_BM128_MIN overrides)
   static const int bm128_min = [] { const char* e = getenv("SDMI_BM128_MIN"); return e ? atoi(e) : 128; }();
-  const bool bm128 = p.M > 64 && tiles128 >= bm128_min;
+  const int opt_bm = sdmi_option("bm128_min");
+  const bool bm128 = p.M > 64 && tiles128 >= (opt_bm > 0 ? opt_bm : bm128_min);
   if (bm128 && bn128) return 1;
   if (bm128) return 2;
   if (bn128) return 3;
