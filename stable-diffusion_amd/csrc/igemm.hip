@@ -1015,14 +1015,13 @@ static int64_t splitk_ws_bytes(int m, int n, int nk, int batch, int rows_per_sam
   if (s < 2) return 0;
   const int kps = (nk + s - 1) / s;
   const int splits = (nk + kps - 1) / kps;
-  return (int64_t)splits * batch * m * ((n + 3) / 4 * 4) * (int64_t)sizeof(float);
+  return SDMI_WS_TICKET_BYTES + (int64_t)splits * batch * m * ((n + 3) / 4 * 4) * (int64_t)sizeof(float);
 }
 
-// Tickets of the in-kernel split-K reduction: zero at load, re-armed by the reducing block.  16 banks of 4096 tiles,
-// bank chosen from the workspace address: split-K launches that overlap in time on one device (different streams) must
-// use different workspaces; launches on one stream, or otherwise ordered, can share one.
-constexpr int SK_TICKET_TILES = 4096, SK_TICKET_BANKS = 16;
-__device__ unsigned g_sk_ticket[SK_TICKET_BANKS * SK_TICKET_TILES];
+// Tickets of the in-kernel split-K reduction (SDMI_F_WS_TICKETS): the first SDMI_WS_TICKET_BYTES of the caller's workspace,
+// one counter per output tile, zeroed once by sdmi_ws_tickets_init and re-armed by the reducing block of every launch.
+// The partial sums start behind them (for every split-K launch, flag or not: one layout).
+constexpr int SK_TICKET_TILES = SDMI_WS_TICKET_BYTES / 4;
 
 // One tile variant: BM x BN block tile, WM x WN waves (wave tile BM/WM x BN/WN), NSTAGE ring slots in dynamic LDS.
 struct TileVariant { int bm, bn, wm, wn, nstage; };
@@ -1130,7 +1129,7 @@ template <bool CONV>
 static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st, const sdmi_epilogue_ext* ext = nullptr) {
   p.ws = nullptr;
   const int vi = plan_igemm<CONV>(p, batch, ws != nullptr, ws_bytes);
-  if (p.splits > 1) p.ws = (float*)ws;
+  if (p.splits > 1) p.ws = (float*)((char*)ws + SDMI_WS_TICKET_BYTES);
   const TileVariant& tv = kVariants[vi];
   const int bm = tv.bm, bn = tv.bn;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
@@ -1172,23 +1171,12 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     const long long wpanel = (long long)p.N * p.K, apanel = (long long)p.M * (CONV && !sdmi_option("conv_nmajor_by_rows") ? p.K / 9 : p.K);
     p.nmajor = force >= 0 ? force : (wpanel > apanel ? 1 : 0);
   }
+  // SDMI_F_WS_TICKETS (opt-in): the block that draws a tile's last ticket sums the partials in split order and runs the
+  // epilogue itself (same bits as the reduce kernel).  Measured slower both rounds (round 1: 10.9 against 10.3 ms per
+  // step; round 2, two concurrent batch-1 passes: 9.01 against 8.51 ms, single convs +4 ... 15 us): the reducing block's
+  // serial read of every partial tile costs more than the 7-13 us launch it replaces.
   p.ticket = nullptr;
-  // Opt-in (SDMI_SPLITK_INKERNEL=1): bit-identical to the reduce kernel, but measured SLOWER on the UNet step (10.9 ms
-  // against 10.3: the reducing block's serial read of every partial tile plus write-through stores cost more than the
-  // 7-13 us reduce launch they replace; with a release fence instead of write-through stores 11.5 ms).
-  static const bool inkernel = [] { const char* e = getenv("SDMI_SPLITK_INKERNEL"); return e && e[0] == '1'; }();
-  if (p.splits > 1 && (long long)nb * batch <= SK_TICKET_TILES && inkernel) {
-    static void* sym_of_device[64] = {};  // every device holds its own copy of the array at its own address
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    void*& sym = sym_of_device[dev & 63];
-    if (!sym && (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sk_ticket)) != hipSuccess || !sym)) {
-      sym = nullptr;
-      sdmi_set_error("split-K: hipGetSymbolAddress(g_sk_ticket) failed");
-      return SDMI_ELAUNCH;
-    }
-    p.ticket = (unsigned*)sym + (((uintptr_t)ws >> 8) % SK_TICKET_BANKS) * SK_TICKET_TILES;
-  }
+  if (p.splits > 1 && (p.flags & SDMI_F_WS_TICKETS) && (long long)nb * batch <= SK_TICKET_TILES) p.ticket = (unsigned*)ws;
   dim3 grid(nb, batch, p.splits);
   if constexpr (CONV) {
     // stride-1 pad-1 convs on 128-row tiles: the shared-window kernel (SDMI_CONV_WIN=0 keeps the generic one: A/B switch)
@@ -1366,6 +1354,15 @@ extern "C" int sdmi_conv3x3_ex(const void* x, int ldx, int n, int h, int w, int 
   IgemmParams p;
   conv_params(p, x, ldx, n, h, w, cin, w_packed, cout, hout, wout, stride, pad_t, pad_l, bias, rowbias, ldrb, residual, ldr, out, ldc, flags);
   return launch_igemm<true>(p, 1, ws, ws_bytes, (hipStream_t)stream, ext);
+}
+
+extern "C" int sdmi_ws_tickets_init(void* ws, void* stream) {
+  SDMI_REQUIRE(ws && ((uintptr_t)ws & 15) == 0, "ws_tickets_init: workspace must be a 16-byte aligned device pointer");
+  if (hipMemsetAsync(ws, 0, SDMI_WS_TICKET_BYTES, (hipStream_t)stream) != hipSuccess) {
+    sdmi_set_error("ws_tickets_init: hipMemsetAsync failed");
+    return SDMI_ELAUNCH;
+  }
+  return 0;
 }
 
 extern "C" int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags) {

@@ -196,8 +196,15 @@ def _workspace(device, nbytes):
             _WS_RETIRED.append(t)       # a captured HIP graph may still address it: never freed (sizes double, so the
             nbytes = max(nbytes, 2 * t.numel() * 4)   # retired buffers add up to less than the live one)
         t = torch.empty(((max(nbytes, 64 << 20) + 3) // 4,), dtype=torch.float32, device=device)
+        L.call("sdmi_ws_tickets_init", t.data_ptr(), _stream())     # arrival counters of the in-launch split-K reduction
         _WS[key] = t
     return t.data_ptr(), t.numel() * 4
+
+
+# SDMI_SPLITK_INKERNEL=1: split-K launches finish inside the launch (SDMI_F_WS_TICKETS; the workspace above is private to a
+# stream, as that needs) instead of by the separate reduce kernel.  Off: bit-identical but measured slower (UNet step 9.01
+# against 8.51 ms, single convs +4 ... 15 us: profiles/r02_splitk_tickets.txt)
+WS_FLAGS = L.F_WS_TICKETS if os.environ.get("SDMI_SPLITK_INKERNEL", "0") == "1" else 0
 
 
 def _check_out(res, n, h, w, c, what):
@@ -325,7 +332,7 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
     if ext is None and isinstance(res, Act):
         res.stats.pop(res.off, None)
     L.call("sdmi_conv3x3_ex", a.ptr, a.ld, a.n, a.h, a.w, cin, wp.data_ptr(), cout, ho, wo, stride, pt, pl,
-           _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags, ws, wsb, _stream(),
+           _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags | (WS_FLAGS if ws else 0), ws, wsb, _stream(),
            ctypes.addressof(ext) if ext is not None else 0)
     return res
 
@@ -375,7 +382,7 @@ def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shap
         res.stats.pop(res.off, None)
     ws, wsb = _workspace(a.device, L.load().sdmi_gemm_ws_bytes(m, n_out, a.c, 1, a.hw, flags))
     L.call("sdmi_gemm_ex", a.ptr, a.ld, 0, wp.data_ptr(), wp.shape[1], 0, res.ptr, res.ld, 0, m, n_out, a.c, 1,
-           _ptr(bias), 0, 0, a.hw, res_ptr, ldr, 1.0, flags, ws, wsb, _stream(),
+           _ptr(bias), 0, 0, a.hw, res_ptr, ldr, 1.0, flags | (WS_FLAGS if ws else 0), ws, wsb, _stream(),
            ctypes.addressof(ext) if ext is not None else 0)
     return res
 

@@ -558,3 +558,50 @@ def test_causal_attention_and_gelu_kernels():
     keep = x[:, 256:].clone()
     L.call("sdmi_gelu_rows", x.data_ptr(), 264, 50, 256, E._stream())
     assert torch.equal(x[:, 256:], keep) and float((x[:, :256].float() - ref.float()).abs().max()) < 4e-3 * _tol()
+
+
+# ------------------------------------------------------------------ split-K finished inside the launch (SDMI_F_WS_TICKETS)
+@pytest.mark.gpu
+def test_splitk_ticketed_workspace_equals_reduce_kernel():
+    """The in-launch reduction gives the bits of the separate reduce kernel, leaves the ticket head zero, and works
+    repeatedly on one workspace; conv and GEMM, through the raw ABI."""
+    import ctypes as C
+    lib = L.load()
+    rs = np.random.RandomState(12)
+    H = E.act_dtype()
+    n, cin, cout, h = 2, 512, 256, 6
+    x = torch.from_numpy(rs.randn(n, h * h, cin).astype(np.float32)).to(DEV).to(H)
+    W = torch.nn.Parameter(torch.from_numpy((rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)).to(DEV))
+    wp = E.packed_conv3x3(W)
+    bias = torch.from_numpy(rs.randn(cout).astype(np.float32)).to(DEV)
+    nbytes = lib.sdmi_conv3x3_ws_bytes(n, cin, cout, h, h)
+    assert nbytes > L.WS_TICKET_BYTES
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=DEV).fill_(float("nan"))
+    assert lib.sdmi_ws_tickets_init(C.c_void_p(ws.data_ptr()), C.c_void_p(E._stream())) == 0
+    outs = []
+    for flags in (L.F_BIAS, L.F_BIAS | L.F_WS_TICKETS, L.F_BIAS | L.F_WS_TICKETS):
+        o = torch.zeros((n, h * h, cout), dtype=H, device=DEV)
+        L.call("sdmi_conv3x3", x.data_ptr(), cin, n, h, h, cin, wp.data_ptr(), cout, h, h, 1, 1, 1, bias.data_ptr(), 0, 0, 0, 0,
+               o.data_ptr(), cout, flags, ws.data_ptr(), nbytes, E._stream())
+        kern = lib.sdmi_last_kernel().decode()
+        assert ("splitk_reduce" in kern) == (flags == L.F_BIAS), kern
+        outs.append(o)
+        assert bool((ws[:L.WS_TICKET_BYTES // 4].view(torch.int32) == 0).all())       # re-armed
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    ref = torch.nn.functional.conv2d(x.float().reshape(n, h, h, cin).permute(0, 3, 1, 2), W.to(H).float(), bias, padding=1)
+    e = rel_err(outs[1].float().reshape(n, h, h, cout).permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy())
+    assert e[1] < 6e-4 * _tol(), e
+    m, nn_, k = 288, 1280, 5120
+    a = torch.from_numpy(rs.randn(m, k).astype(np.float32)).to(DEV).to(H)
+    w2 = torch.from_numpy((rs.randn(nn_, k) / np.sqrt(k)).astype(np.float32)).to(DEV).to(H)
+    gb = lib.sdmi_gemm_ws_bytes(m, nn_, k, 1, 144, 0)
+    assert gb > L.WS_TICKET_BYTES
+    ws2 = torch.empty((gb // 4,), dtype=torch.float32, device=DEV)
+    lib.sdmi_ws_tickets_init(C.c_void_p(ws2.data_ptr()), C.c_void_p(E._stream()))
+    og = []
+    for flags in (0, L.F_WS_TICKETS):
+        o = torch.zeros((m, nn_), dtype=H, device=DEV)
+        L.call("sdmi_gemm", a.data_ptr(), k, 0, w2.data_ptr(), k, 0, o.data_ptr(), nn_, 0, m, nn_, k, 1, 0, 0, 0, 144, 0, 0, 1.0,
+               flags, ws2.data_ptr(), gb, E._stream())
+        og.append(o)
+    assert torch.equal(og[0], og[1])
