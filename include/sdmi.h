@@ -109,15 +109,17 @@ int64_t sdmi_conv3x3_ws_bytes(int n, int cin, int cout, int hout, int wout);
 
 /* Split-K without the second kernel (sdmi_conv3x3 / sdmi_gemm and their _ex forms): with SDMI_F_WS_TICKETS in `flags` the
  * block that finishes an output tile last sums the partials (same fixed order, same bits) and runs the epilogue itself.
- * It counts arrivals in the first SDMI_WS_TICKET_BYTES of `ws` (the sdmi_*_ws_bytes figures include them; the partial sums
- * always start behind them), which the caller zeroes ONCE per workspace with sdmi_ws_tickets_init and every launch leaves
- * zeroed again.  A workspace used this way serves launches that are ordered against each other (one stream, or one
- * chain of a graph); launches that may overlap in time need a workspace each.  No reference counterpart (the reference
- * has no split-K).  Opt-in: it takes one launch off the dependent chain of an under-filled conv / GEMM, but measured
- * slower than the reduce kernel on MI355X at the UNet's shapes. */
+ * Arrivals are counted in a bank of library-owned device counters that belongs to ONE workspace: sdmi_ws_tickets_init(ws)
+ * registers a workspace on the current device (16 banks per device: SDMI_EINVAL when all are taken;
+ * sdmi_ws_tickets_release(ws) gives a bank back once no launch or captured graph uses the workspace any more).  A
+ * launch with the flag on an unregistered workspace runs the reduce kernel as usual.  A workspace serves launches that
+ * are ordered against each other (one stream, one chain of a graph); launches that may overlap in time need a workspace
+ * each - with or without the flag - and therefore never share counters.  No reference counterpart (the reference has no
+ * split-K).  Opt-in: it takes one launch off the dependent chain of an under-filled conv / GEMM, but measured slower
+ * than the reduce kernel on MI355X at the UNet's shapes. */
 #define SDMI_F_WS_TICKETS 1024u
-#define SDMI_WS_TICKET_BYTES 16384
 int sdmi_ws_tickets_init(void* ws, void* stream);
+int sdmi_ws_tickets_release(void* ws);
 
 /* ---- first-layer conv with tiny Cin reading the caller's NCHW fp32 tensor directly:
  *      Unet.py:49 (9->320), AutoencoderKL.py:136 (4->512), :61 (3->128).  w is the fp32 OIHW weight. */

@@ -13,7 +13,6 @@ LIB_PATH = os.environ.get("SDMI_LIB_PATH") or os.path.join(_HERE, "libsdmi355.so
 F_BIAS, F_ROWBIAS, F_RESIDUAL, F_GEGLU, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_SILU, F_OUT_F32, F_OUT_U8_IMAGE = 1, 2, 4, 8, 16, 32, 64, 128, 256
 F_LNFOLD = 512
 F_WS_TICKETS = 1024
-WS_TICKET_BYTES = 16384
 
 
 class EpilogueExt(C.Structure):
@@ -71,6 +70,7 @@ PROTOTYPES = {
     "sdmi_embed_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sdmi_gelu_rows": (_i, [_vp, _i, _i, _i, _vp]),
     "sdmi_ws_tickets_init": (_i, [_vp, _vp]),
+    "sdmi_ws_tickets_release": (_i, [_vp]),
     "sdmi_attention_log2q": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "sdmi_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "sdmi_cfg_ddim_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -19,6 +19,7 @@
 // Built with -mllvm -amdgpu-mfma-vgpr-form (Makefile): accumulators stay in arch VGPRs, 3-10 % faster here.
 #include <stdlib.h>
 #include "common.h"
+#include <mutex>
 
 struct IgemmParams {
   const u16* a; const u16* w; void* out; const float* bias; const float* rowbias; const u16* res;
@@ -1015,13 +1016,43 @@ static int64_t splitk_ws_bytes(int m, int n, int nk, int batch, int rows_per_sam
   if (s < 2) return 0;
   const int kps = (nk + s - 1) / s;
   const int splits = (nk + kps - 1) / kps;
-  return SDMI_WS_TICKET_BYTES + (int64_t)splits * batch * m * ((n + 3) / 4 * 4) * (int64_t)sizeof(float);
+  return (int64_t)splits * batch * m * ((n + 3) / 4 * 4) * (int64_t)sizeof(float);
 }
 
-// Tickets of the in-kernel split-K reduction (SDMI_F_WS_TICKETS): the first SDMI_WS_TICKET_BYTES of the caller's workspace,
-// one counter per output tile, zeroed once by sdmi_ws_tickets_init and re-armed by the reducing block of every launch.
-// The partial sums start behind them (for every split-K launch, flag or not: one layout).
-constexpr int SK_TICKET_TILES = SDMI_WS_TICKET_BYTES / 4;
+// Tickets of the in-launch split-K reduction (SDMI_F_WS_TICKETS): one arrival counter per output tile, zero at load and
+// re-armed by the reducing block of every launch, in this library-owned array.  A bank of counters belongs to ONE
+// registered workspace (sdmi_ws_tickets_init), so launches that may overlap in time - which need different workspaces
+// anyway - never share counters.  (Round 1 picked the bank from a hash of the workspace address: two 64 MB-aligned
+// workspaces of two concurrent streams hashed to the same bank.)
+constexpr int SK_TICKET_TILES = 4096, SK_TICKET_BANKS = 16;
+__device__ unsigned g_sk_ticket[SK_TICKET_BANKS * SK_TICKET_TILES];
+struct TicketBanks {
+  std::mutex mu;
+  const void* owner[64][SK_TICKET_BANKS] = {};  // [device][bank] -> registered workspace
+  unsigned* base[64] = {};                       // device address of g_sk_ticket on that device
+};
+static TicketBanks g_banks;
+// bank of a registered workspace on the current device, or nullptr; reg: claim a free bank if it has none yet
+static unsigned* ticket_bank(const void* ws, bool reg, bool* full = nullptr) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 63;
+  std::lock_guard<std::mutex> lock(g_banks.mu);
+  if (!g_banks.base[dev]) {
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sk_ticket)) != hipSuccess || !sym) return nullptr;
+    g_banks.base[dev] = (unsigned*)sym;
+  }
+  int free_bank = -1;
+  for (int b = 0; b < SK_TICKET_BANKS; ++b) {
+    if (g_banks.owner[dev][b] == ws) return g_banks.base[dev] + b * SK_TICKET_TILES;
+    if (!g_banks.owner[dev][b] && free_bank < 0) free_bank = b;
+  }
+  if (!reg) return nullptr;
+  if (free_bank < 0) { if (full) *full = true; return nullptr; }
+  g_banks.owner[dev][free_bank] = ws;
+  return g_banks.base[dev] + free_bank * SK_TICKET_TILES;
+}
 
 // One tile variant: BM x BN block tile, WM x WN waves (wave tile BM/WM x BN/WN), NSTAGE ring slots in dynamic LDS.
 struct TileVariant { int bm, bn, wm, wn, nstage; };
@@ -1129,7 +1160,7 @@ template <bool CONV>
 static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st, const sdmi_epilogue_ext* ext = nullptr) {
   p.ws = nullptr;
   const int vi = plan_igemm<CONV>(p, batch, ws != nullptr, ws_bytes);
-  if (p.splits > 1) p.ws = (float*)((char*)ws + SDMI_WS_TICKET_BYTES);
+  if (p.splits > 1) p.ws = (float*)ws;
   const TileVariant& tv = kVariants[vi];
   const int bm = tv.bm, bn = tv.bn;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
@@ -1172,11 +1203,12 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     p.nmajor = force >= 0 ? force : (wpanel > apanel ? 1 : 0);
   }
   // SDMI_F_WS_TICKETS (opt-in): the block that draws a tile's last ticket sums the partials in split order and runs the
-  // epilogue itself (same bits as the reduce kernel).  Measured slower both rounds (round 1: 10.9 against 10.3 ms per
-  // step; round 2, two concurrent batch-1 passes: 9.01 against 8.51 ms, single convs +4 ... 15 us): the reducing block's
-  // serial read of every partial tile costs more than the 7-13 us launch it replaces.
+  // epilogue itself (same bits as the reduce kernel).  Measured slower both rounds (round 1, one batch-2 pass: 10.9 against
+  // 10.3 ms per step; round 2, two concurrent batch-1 passes: 8.82 against 8.28 ms; single convs +4 ... 15 us): the reducing
+  // block's serial read of every partial tile costs more than the 7-13 us launch it replaces.
   p.ticket = nullptr;
-  if (p.splits > 1 && (p.flags & SDMI_F_WS_TICKETS) && (long long)nb * batch <= SK_TICKET_TILES) p.ticket = (unsigned*)ws;
+  if (p.splits > 1 && (p.flags & SDMI_F_WS_TICKETS) && (long long)nb * batch <= SK_TICKET_TILES)
+    p.ticket = ticket_bank(ws, false);  // an unregistered workspace (or none free at registration): the reduce kernel
   dim3 grid(nb, batch, p.splits);
   if constexpr (CONV) {
     // stride-1 pad-1 convs on 128-row tiles: the shared-window kernel (SDMI_CONV_WIN=0 keeps the generic one: A/B switch)
@@ -1357,12 +1389,26 @@ extern "C" int sdmi_conv3x3_ex(const void* x, int ldx, int n, int h, int w, int 
 }
 
 extern "C" int sdmi_ws_tickets_init(void* ws, void* stream) {
-  SDMI_REQUIRE(ws && ((uintptr_t)ws & 15) == 0, "ws_tickets_init: workspace must be a 16-byte aligned device pointer");
-  if (hipMemsetAsync(ws, 0, SDMI_WS_TICKET_BYTES, (hipStream_t)stream) != hipSuccess) {
-    sdmi_set_error("ws_tickets_init: hipMemsetAsync failed");
-    return SDMI_ELAUNCH;
+  (void)stream;
+  SDMI_REQUIRE(ws, "ws_tickets_init: null workspace");
+  bool full = false;
+  if (!ticket_bank(ws, true, &full)) {
+    sdmi_set_error(full ? "ws_tickets_init: all %d counter banks of this device are taken (release one with sdmi_ws_tickets_release)"
+                        : "ws_tickets_init: hipGetSymbolAddress(g_sk_ticket) failed", SK_TICKET_BANKS);
+    return full ? SDMI_EINVAL : SDMI_ELAUNCH;
   }
   return 0;
+}
+
+extern "C" int sdmi_ws_tickets_release(void* ws) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 63;
+  std::lock_guard<std::mutex> lock(g_banks.mu);
+  for (int b = 0; b < SK_TICKET_BANKS; ++b)
+    if (g_banks.owner[dev][b] == ws) { g_banks.owner[dev][b] = nullptr; return 0; }
+  sdmi_set_error("ws_tickets_release: workspace is not registered on this device");
+  return SDMI_EINVAL;
 }
 
 extern "C" int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags) {

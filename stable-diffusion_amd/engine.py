@@ -196,14 +196,17 @@ def _workspace(device, nbytes):
             _WS_RETIRED.append(t)       # a captured HIP graph may still address it: never freed (sizes double, so the
             nbytes = max(nbytes, 2 * t.numel() * 4)   # retired buffers add up to less than the live one)
         t = torch.empty(((max(nbytes, 64 << 20) + 3) // 4,), dtype=torch.float32, device=device)
-        L.call("sdmi_ws_tickets_init", t.data_ptr(), _stream())     # arrival counters of the in-launch split-K reduction
+        # a bank of arrival counters for the in-launch split-K reduction; when all 16 banks of the device are taken
+        # (many samplers alive at once) this workspace simply keeps the separate reduce kernel
+        import ctypes as C
+        L.load().sdmi_ws_tickets_init(C.c_void_p(t.data_ptr()), C.c_void_p(_stream()))
         _WS[key] = t
     return t.data_ptr(), t.numel() * 4
 
 
 # SDMI_SPLITK_INKERNEL=1: split-K launches finish inside the launch (SDMI_F_WS_TICKETS; the workspace above is private to a
-# stream, as that needs) instead of by the separate reduce kernel.  Off: bit-identical but measured slower (UNet step 9.01
-# against 8.51 ms, single convs +4 ... 15 us: profiles/r02_splitk_tickets.txt)
+# stream, as that needs) instead of by the separate reduce kernel.  Off: bit-identical but measured slower (UNet step 8.82
+# against 8.28 ms, single convs +4 ... 15 us: profiles/r02_splitk_tickets.txt)
 WS_FLAGS = L.F_WS_TICKETS if os.environ.get("SDMI_SPLITK_INKERNEL", "0") == "1" else 0
 
 

