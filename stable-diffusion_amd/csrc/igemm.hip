@@ -1108,7 +1108,9 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
     // than two 128x128 ones; grids too small for that run the smallest tile, except long-K wide-N ones (weights are the
     // traffic there).  From the sweep of the UNet's shapes, scratch/tune_sweep.py.
     const long long b2 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * batch * p.splits;
-    if (b2 >= 600) return 2;
+    const int t2_min = sdmi_option("gemm_t2_min_blocks");
+    // (round 2, two concurrent batch-1 passes: 360 instead of 600 - the 9216 x 320 GEMMs of one CFG half - step -1.1 %)
+    if (b2 >= (t2_min > 0 ? t2_min : 360)) return 2;
     // (64 x 128 only with enough rows: at M = 576 / 144, one CFG half of the 24x24 / 12x12 levels, 64 x 64 ran 1.1 - 1.6x
     // faster on the K >= 2048 GEMMs: scratch/gemm_sweep_b1.py)
     if (p.K >= 2048 && p.N >= 1024 && (p.M >= 1024 || !sdmi_option("gemm_small_m_tile"))) return 3;
