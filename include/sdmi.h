@@ -148,7 +148,8 @@ int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, 
  *      - SDMI_F_LNFOLD: this GEMM consumes such row statistics and computes LayerNorm(x) @ W^T without a LayerNorm pass:
  *        w was packed by sdmi_pack_linear_ln (gamma folded into the weights), the epilogue applies
  *        out = rstd[m] * (acc - mean[m] * ln_u[n]) + bias[n], bias = the ln_v of sdmi_pack_linear_ln.
- *      sdmi_*_stats_parts tell how many parts a problem writes (0 = it cannot: split-K, odd shapes); asking for statistics
+ *      sdmi_*_stats_parts tell how many parts a problem writes (0 = it cannot: odd shapes; a split-K launch leaves colstats
+ *      from its reduce kernel but no rowstats); asking for statistics
  *      a launch cannot deliver is an error, never a silent skip. */
 #define SDMI_F_LNFOLD 512u
 typedef struct sdmi_epilogue_ext {

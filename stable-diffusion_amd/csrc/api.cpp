@@ -51,6 +51,7 @@ static struct { const char* name; int value; } g_options[] = {
     {"splitk_min_kt_gemm", 0},  // > 0: same for plain GEMMs (default 24; round 1: 32)
     {"bm128_min", 0},           // > 0: 128-row tiles once they number at least this (default 128)
     {"gemm_t2_min_blocks", 0},  // > 0: plain GEMMs take 128 x 64 tiles once those number at least this (default 360; round 1: 600)
+    {"split_colstats_off", 0},  // 1: split-K launches leave no column statistics (A/B switch)
     {"gemm_small_m_tile", 1},   // 1: 64x64 tiles for K >= 2048 GEMMs with fewer than 1024 rows (0: 64x128 as in round 1)
     {"attn_x2_min_nq", 0},      // > 0: query rows from which long self-attention takes the 64-rows-per-wave kernel (default 2048)
     {"attn_variant", 0},        // attention kernel variant (0 = default)

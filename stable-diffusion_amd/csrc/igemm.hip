@@ -137,6 +137,52 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
   }
 }
 
+// The same, leaving per-channel (sum, sumsq) of every 32-row part for the GroupNorm that follows (colstats, as the fast
+// epilogue of an unsplit launch does): a block owns 32 rows x 32 columns, a thread one row's 4 columns; the 32 rows of a
+// column are summed over the 8 rows of a wave by shuffles and over the 4 waves through the LDS, in a fixed order.  batch 1.
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_stats_kernel(const IgemmParams p, float* __restrict__ colstats) {
+  __shared__ float sm[4][8][8];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int chunks = (p.N + 31) / 32;
+  const int part = blockIdx.x / chunks, chunk = blockIdx.x - part * chunks;
+  const int m = part * 32 + (t >> 3), n0 = chunk * 32 + (t & 7) * 4;
+  const long long per_split = (long long)p.M * p.npad;
+  float y[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool live = n0 < p.N;  // N % 4 == 0 on this path (host): a thread's 4 columns are all inside or all outside
+  if (live) {
+    const float* src = p.ws + (long long)m * p.npad + n0;
+    float4 a = *(const float4*)src;
+    for (int s = 1; s < p.splits; ++s) {
+      const float4 b = *(const float4*)(src + s * per_split);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w;
+    epilogue4(p, 0, m, n0, y);
+  }
+  float sq[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sq[e] = live ? y[e] : 0.f; sq[4 + e] = sq[e] * sq[e]; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {  // over the wave's 8 rows: lanes l, l ^ 8, l ^ 16, l ^ 32 hold the same columns
+    sq[e] += __shfl_xor(sq[e], 8);
+    sq[e] += __shfl_xor(sq[e], 16);
+    sq[e] += __shfl_xor(sq[e], 32);
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[wv][lane][e] = sq[e];
+  }
+  __syncthreads();
+  if (t < 32) {  // column chunk*32 + t: thread t's column sits in lane group t >> 2, element t & 3
+    const int g = t >> 2, e = t & 3, n = chunk * 32 + t;
+    if (n < p.N) {
+      const float s = ((sm[0][g][e] + sm[1][g][e]) + sm[2][g][e]) + sm[3][g][e];
+      const float q = ((sm[0][g][4 + e] + sm[1][g][4 + e]) + sm[2][g][4 + e]) + sm[3][g][4 + e];
+      *(float2*)(colstats + ((long long)part * p.N + n) * 2) = make_float2(s, q);
+    }
+  }
+}
+
 
 // ---- fast epilogue.  The MFMA layout leaves a lane with 4 channels of one row (8-byte pieces, a dependent bias /
 // residual load each).  Lanes l and l^16 hold neighbouring 4-channel pieces of the same row, so for every pair of
@@ -1154,7 +1200,10 @@ static void stats_parts_of(const IgemmParams& p, int batch, int vi, int* row_par
   const int tm = tv.bm / tv.wm, tn = tv.bn / tv.wn;
   const bool plain = p.splits == 1 && batch == 1 && p.N % 8 == 0 &&
                      !(p.flags & (SDMI_F_GEGLU | SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE | SDMI_F_OUT_F32)) && tn >= 32 && tm >= 32;
-  if (row_parts) *row_parts = (plain && p.M % tm == 0 && p.rows_per_sample % 32 == 0) ? p.M / 32 : 0;
+  // a split-K launch leaves the column statistics from its reduce kernel (igemm_splitk_reduce_stats_kernel)
+  const bool split_cs = p.splits > 1 && batch == 1 && p.N % 4 == 0 && p.M % 32 == 0 && !sdmi_option("split_colstats_off") &&
+                        !(p.flags & (SDMI_F_GEGLU | SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE | SDMI_F_OUT_F32));
+  if (row_parts) *row_parts = (((plain && p.M % tm == 0) || split_cs) && p.rows_per_sample % 32 == 0) ? p.M / 32 : 0;
   if (col_parts) *col_parts = (plain && p.N % 32 == 0) ? p.N / 32 : 0;
 }
 
@@ -1167,6 +1216,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   const int bm = tv.bm, bn = tv.bn;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   p.colstats = nullptr; p.rowstats = nullptr; p.ln_stats = nullptr; p.ln_u = nullptr; p.ln_parts = 0; p.col_parts = 0; p.ln_eps = 0.f;
+  float* split_colstats = nullptr;
   if (ext) {
     int rparts = 0, cparts = 0;
     stats_parts_of(p, batch, vi, &rparts, &cparts);
@@ -1174,6 +1224,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     SDMI_REQUIRE(!ext->rowstats || cparts > 0, "%s: this problem cannot emit rowstats (ask sdmi_*_stats_parts first)", CONV ? "conv3x3" : "gemm");
     SDMI_REQUIRE((((uintptr_t)ext->colstats | (uintptr_t)ext->rowstats) & 15) == 0, "epilogue ext: statistics buffers must be 16-byte aligned");
     p.colstats = ext->colstats; p.rowstats = ext->rowstats; p.col_parts = cparts;
+    if (p.splits > 1) { split_colstats = p.colstats; p.colstats = nullptr; }  // written by the reduce kernel, not by the main one
     if (p.flags & SDMI_F_LNFOLD) {
       SDMI_REQUIRE(!CONV && ext->ln_rowstats && ext->ln_u && ext->ln_parts > 0 && ext->ln_eps > 0.f, "gemm: SDMI_F_LNFOLD needs ln_rowstats, ln_u, ln_parts, ln_eps");
       SDMI_REQUIRE(batch == 1 && p.splits == 1 && !(p.flags & (SDMI_F_ROWBIAS | SDMI_F_OUT_NCHW_F32)), "gemm: SDMI_F_LNFOLD with batch / split-K / rowbias / NCHW output");
@@ -1209,7 +1260,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   // 10.3 ms per step; round 2, two concurrent batch-1 passes: 8.82 against 8.28 ms; single convs +4 ... 15 us): the reducing
   // block's serial read of every partial tile costs more than the 7-13 us launch it replaces.
   p.ticket = nullptr;
-  if (p.splits > 1 && (p.flags & SDMI_F_WS_TICKETS) && (long long)nb * batch <= SK_TICKET_TILES)
+  if (p.splits > 1 && !split_colstats && (p.flags & SDMI_F_WS_TICKETS) && (long long)nb * batch <= SK_TICKET_TILES)
     p.ticket = ticket_bank(ws, false);  // an unregistered workspace (or none free at registration): the reduce kernel
   dim3 grid(nb, batch, p.splits);
   if constexpr (CONV) {
@@ -1235,14 +1286,15 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         else hipLaunchKernelGGL((conv_win_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);
       }
       sdmi_note_kernel("conv_win_kernel<128, %d, %s>%s", bn, p.colstats ? "true" : "false",
-                       (p.splits > 1 && !p.ticket) ? " + igemm_splitk_reduce_kernel" : "");
+                       (p.splits > 1 && !p.ticket) ? (split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
       int rcw = sdmi_check_launch("conv3x3 (shared window)");
       if (rcw || p.splits < 2 || p.ticket) return rcw;
       long long items = (long long)batch * p.M * (p.npad / 4);
       long long rb = (items + 255) / 256;
       if (rb > 4096) rb = 4096;
       record_mid_event(st);
-      hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
+      if (split_colstats) hipLaunchKernelGGL(igemm_splitk_reduce_stats_kernel, dim3((unsigned)((p.M / 32) * ((p.N + 31) / 32))), dim3(256), 0, st, p, split_colstats);
+      else hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
       return sdmi_check_launch("split-K reduce");
     }
   }
@@ -1264,14 +1316,15 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
       break;
   }
   sdmi_note_kernel("igemm_kernel<%d, %d, %d, %d, %s, %d, %s>%s", bm, bn, tv.wm, tv.wn, CONV ? "true" : "false", tv.nstage,
-                   (p.flags & SDMI_F_GEGLU) ? "true" : "false", (p.splits > 1 && !p.ticket) ? " + igemm_splitk_reduce_kernel" : "");
+                   (p.flags & SDMI_F_GEGLU) ? "true" : "false", (p.splits > 1 && !p.ticket) ? (split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
   int rc = sdmi_check_launch(CONV ? "conv3x3" : "gemm");
   if (rc || p.splits < 2 || p.ticket) return rc;
   long long items = (long long)batch * p.M * (p.npad / 4);
   long long rb = (items + 255) / 256;
   if (rb > 4096) rb = 4096;
   record_mid_event(st);
-  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
+  if (split_colstats) hipLaunchKernelGGL(igemm_splitk_reduce_stats_kernel, dim3((unsigned)((p.M / 32) * ((p.N + 31) / 32))), dim3(256), 0, st, p, split_colstats);
+  else hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
   return sdmi_check_launch("split-K reduce");
 }
 

@@ -293,7 +293,7 @@ def test_resblock_large_vs_oracle_with_colstats(hh, cin, cout):
             emb = E.linear_small_m(temb.to(DEV), E.packed_linear((m.emb_proj.weight,)), m.emb_proj.bias, silu_in=True)
             y = m.run(a, emb, emb.shape[1])
             outs[mode] = E.to_nchw(y)
-            if mode and hh >= 96:       # (at 48x48 and batch 1 the convs run split-K: no statistics, the re-reading path)
+            if mode:                    # (at 48x48 and batch 1 the convs run split-K: their reduce kernel leaves the statistics)
                 assert y.stats, "conv2 left no statistics"
         finally:
             E.USE_COLSTATS = saved
@@ -593,7 +593,7 @@ def test_splitk_ticketed_workspace_equals_reduce_kernel():
     o3, k3 = conv(L.F_BIAS | L.F_WS_TICKETS)                      # counters were re-armed by the launch before
     assert "splitk_reduce" not in k2 and "splitk_reduce" not in k3
     assert torch.equal(o0, o1) and torch.equal(o0, o2) and torch.equal(o0, o3)
-    ref = torch.nn.functional.conv2d(x.float().reshape(n, h, h, cin).permute(0, 3, 1, 2), W.to(H).float(), bias, padding=1)
+    ref = torch.nn.functional.conv2d(x.float().reshape(n, h, h, cin).permute(0, 3, 1, 2), W.detach().to(H).float(), bias, padding=1)
     e = rel_err(o2.float().reshape(n, h, h, cout).permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy())
     assert e[1] < 6e-4 * _tol(), e
     m, nn_, k = 288, 1280, 5120
@@ -615,3 +615,40 @@ def test_splitk_ticketed_workspace_equals_reduce_kernel():
     assert lib.sdmi_ws_tickets_release(wsp) != 0                  # not registered any more
     _, k4 = conv(L.F_BIAS | L.F_WS_TICKETS)
     assert "splitk_reduce" in k4
+
+
+@pytest.mark.gpu
+def test_splitk_conv_leaves_column_statistics():
+    """A split-K conv (48x48, 640 channels, batch 1) with colstats: its reduce kernel leaves per-channel (sum, sumsq) of every
+    32-row part of the fp32 result; against the sums of the stored output, and the output bits against a launch without
+    statistics."""
+    import ctypes as C
+    lib = L.load()
+    rs = np.random.RandomState(4)
+    H = E.act_dtype()
+    hw, cin, cout = 48, 640, 640
+    x = E.Act(torch.from_numpy(rs.randn(1, hw * hw, cin).astype(np.float32)).to(DEV).to(H), 1, hw, hw, cin)
+    W = torch.nn.Parameter(torch.from_numpy((rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)).to(DEV))
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).to(DEV)
+    saved = E.USE_COLSTATS
+    try:
+        E.USE_COLSTATS = True
+        y1 = E.conv3x3(x, W, b)
+        kern = lib.sdmi_last_kernel().decode()
+        E.USE_COLSTATS = False
+        y0 = E.conv3x3(x, W, b)
+    finally:
+        E.USE_COLSTATS = saved
+    assert "igemm_splitk_reduce_stats_kernel" in kern, kern
+    assert torch.equal(y0.buf, y1.buf)
+    cs, parts, c = y1.stats[0]
+    assert parts == hw * hw // 32 and c == cout and cs.shape == (parts, cout, 2)
+    v = y1.buf[0].float().reshape(parts, 32, cout)          # stored values are the fp32 ones rounded to 16 bits
+    want_s, want_q = v.sum(1), (v * v).sum(1)
+    assert float((cs[..., 0] - want_s).abs().max()) < 2e-2 * _tol() and float(((cs[..., 1] - want_q).abs() / want_q.clamp_min(1.0)).max()) < 2e-3 * _tol()
+    # and the GroupNorm that consumes them agrees with the re-reading kernels
+    gamma = torch.from_numpy((1 + 0.1 * rs.randn(cout)).astype(np.float32)).to(DEV)
+    beta = torch.from_numpy((0.1 * rs.randn(cout)).astype(np.float32)).to(DEV)
+    g1 = E.groupnorm(y1, gamma, beta, 1e-5, silu=True).buf.float()
+    g0 = E.groupnorm(y0, gamma, beta, 1e-5, silu=True).buf.float()
+    assert float((g1 - g0).norm() / g0.norm()) < 6e-4 * _tol()
