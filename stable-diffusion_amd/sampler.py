@@ -39,8 +39,16 @@ def _f32(v):
 
 
 class Sampler(object):
-    def __init__(self, unet, vae=None, dual_stream=None):
+    def __init__(self, unet, vae=None, dual_stream=None, cfg_group=None):
+        """cfg_group: a two-rank torch.distributed group (shard.new_cfg_pair_group).  Its rank 0 evaluates only the
+        unconditional and its rank 1 only the conditional half of every step; the halves are exchanged once per step and
+        both ranks apply the same update (single-image latency mode).  Every rank of the pair must call
+        sample() with the same arguments."""
         self.unet, self.vae = unet, vae
+        self.cfg_group = cfg_group
+        if cfg_group is not None:
+            import torch.distributed as dist
+            self.cfg_role = dist.get_rank(cfg_group)
         self._graph = None
         self._gkey = None
         # dual_stream: evaluate the unconditional and the conditional half of the CFG batch as two independent UNet
@@ -81,15 +89,18 @@ class Sampler(object):
         """Step-invariant text-context K/V of the CFG batch [uncond | cond] (one object per half when dual_stream).
         The objects are owned by the sampler and refilled IN PLACE for every prompt of the same batch size: the captured
         UNet step reads their buffers, so they must not move between images."""
-        key = (tuple(uncond.shape), str(uncond.device), self.dual_stream)
-        halves = (uncond.contiguous(), cond.contiguous()) if self.dual_stream else (torch.cat([uncond, cond]).contiguous(),)
+        key = (tuple(uncond.shape), str(uncond.device), self.dual_stream, self.cfg_group is not None)
+        if self.cfg_group is not None:
+            halves = ((uncond, cond)[self.cfg_role].contiguous(),)      # this rank's half only
+        else:
+            halves = (uncond.contiguous(), cond.contiguous()) if self.dual_stream else (torch.cat([uncond, cond]).contiguous(),)
         if getattr(self, "_cc_key", None) != key:
             self._cc = tuple(self.unet.precompute_context(h) for h in halves)
             self._cc_key = key
         else:
             for c, h in zip(self._cc, halves):
                 c.update(h)
-        return self._cc if self.dual_stream else self._cc[0]
+        return self._cc if (self.dual_stream and self.cfg_group is None) else self._cc[0]
 
     def _static_xc(self, shape, dev):
         """The UNet input buffer [x | mask | masked latent] x [uncond, cond]: static, the captured step reads it."""
@@ -114,6 +125,12 @@ class Sampler(object):
         return eps
 
     def _unet_eval(self, xc, t_buf, cc, same_halves=False):
+        if self.cfg_group is not None:
+            # this rank's half only; the partner's arrives by exchange_cfg_halves() after the (captured) pass
+            b, r = xc.shape[0] // 2, self.cfg_role
+            eps = self._eps_buffer(xc)
+            self.unet.forward_into(xc[r * b:(r + 1) * b], self._half(t_buf, b, r), cc, eps[r * b:(r + 1) * b])
+            return eps
         if not self.dual_stream:
             return self.unet(xc, timesteps=t_buf, context=cc)
         b = xc.shape[0] // 2
@@ -190,6 +207,9 @@ class Sampler(object):
             index = total - i - 1
             emb_cur.table.copy_(emb_table[i])
             eps = self._unet_step(xc, emb_cur, cc, use_graph, same_halves=True)   # xc halves are built identical above
+            if self.cfg_group is not None:
+                from .shard import exchange_cfg_halves
+                exchange_cfg_halves(eps, self.cfg_role, self.cfg_group)
             E.cfg_ddim_step(eps, x, noises[i], scale, _f32(s1m[index]), _f32(a_t[index]), _f32(a_prev[index]),
                             _f32(sig[index]), temperature, x_out=x, xc_out=xc)
             if trace is not None:

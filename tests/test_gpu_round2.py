@@ -187,6 +187,53 @@ def test_two_process_sharded_sampler_equals_unsharded():
     assert ok and all(p.exitcode == 0 for p in procs)
 
 
+def _cfg_pair_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import stable_diffusion_amd
+    stable_diffusion_amd.install_dropin()
+    from Unet import Unet
+    from AutoencoderKL import AutoencoderKL
+    from stable_diffusion_amd.sampler import Sampler
+    from stable_diffusion_amd.shard import new_cfg_pair_group
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = new_cfg_pair_group()
+    torch.set_grad_enabled(False)
+    unet, vae = Unet(), AutoencoderKL()
+    fill_state_dict(unet.state_dict(), seed=0, fast=True)
+    fill_state_dict(vae.state_dict(), seed=1, fast=True)
+    unet, vae = unet.to(DEV).eval(), vae.to(DEV).eval()
+    inp = make_inputs(2, 16, 4, seed=79)
+    dev = lambda t: t.to(DEV)
+    args = (4, dev(inp["cond"]), dev(inp["uncond"]), dev(inp["c_concat"]), dev(inp["x_T"]), [dev(n) for n in inp["noises"]], 9.0)
+    ok = True
+    for use_graph in (False, True):
+        lat, img = Sampler(unet, vae, cfg_group=group).sample(*args, use_graph=use_graph)
+        if rank == 0:
+            rlat, rimg = Sampler(unet, vae).sample(*args, use_graph=use_graph)
+            ok = ok and bool(torch.equal(lat, rlat)) and bool(torch.equal(img, rimg))
+        dist.barrier()
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg_halves_on_two_ranks_equal_one_process():
+    """Single-image latency mode: rank 0 evaluates the unconditional, rank 1 the conditional half of every
+    step and they exchange the noise predictions; latent and image equal one process running both halves, eager and
+    with the captured step (two processes sharing this one GPU, gloo for the exchange; RCCL on a multi-GPU node)."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfg_pair_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    ok = q.get(timeout=110)
+    [p.join(timeout=60) for p in procs]
+    assert ok and all(p.exitcode == 0 for p in procs)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # normalisation fused into the neighbouring kernels: statistics from the producer's epilogue, LayerNorm folded into the
 # consumer GEMM (reference layers/ResBlock.py:65-74, layers/SpatialTransformer.py:182-184, :212)
