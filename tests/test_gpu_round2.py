@@ -492,23 +492,39 @@ def _attn512_ref(q, k, v):
     return torch.softmax(q.double() @ k.double().transpose(-1, -2) * 512.0 ** -0.5, dim=-1) @ v.double()
 
 
+@pytest.fixture
+def d512_variant():
+    lib = L.load()
+    yield lambda v: lib.sdmi_set_option(b"attn_d512_variant", v)
+    lib.sdmi_set_option(b"attn_d512_variant", 0)
+
+
+D512_KERNELS = {0: "attn512w8_kernel", 1: "attn512_kernel", 2: "attn512w8_kernel"}   # 0 = the library's own choice
+
+
 @pytest.mark.gpu
-def test_attention_d512_known_answer(golden):
-    """g5's (1, 130, 512) fp64 known-answer vector through sdmi_attention_d512 (ragged: 130 = 4 tiles + 2 keys)."""
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_attention_d512_known_answer(golden, d512_variant, variant):
+    """g5's (1, 130, 512) fp64 known-answer vector through sdmi_attention_d512 (ragged: 130 = 4 tiles + 2 keys), both
+    kernels (4 waves x 32 rows with recomputed scores; 8 waves x 64 rows with the scores' d-sum split over the waves)."""
+    d512_variant(variant)
     g = golden("g5_attention")
     H = E.act_dtype()
     mk = lambda a: E.Act(torch.from_numpy(a).to(DEV).to(H).contiguous(), 1, 1, a.shape[1], 512)
     o = E.attention_d512(mk(g["vae_q"]), mk(g["vae_k"]), mk(g["vae_v"])).buf.float().cpu()
     e = rel_err(o.numpy(), g["vae_o"])
     assert e[0] < 1.5e-3 * _tol() and e[1] < 6e-4 * _tol(), e
-    assert L.load().sdmi_last_kernel().decode() == "attn512_kernel"
+    assert L.load().sdmi_last_kernel().decode() == D512_KERNELS[variant]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("b,n,kind", [(1, 33, "plain"), (2, 64, "plain"), (1, 1000, "plain"), (2, 257, "wide"), (1, 576, "late_spike")])
-def test_attention_d512_vs_fp64(b, n, kind):
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("b,n,kind", [(1, 33, "plain"), (2, 64, "plain"), (1, 1000, "plain"), (2, 257, "wide"), (1, 576, "late_spike"),
+                                      (1, 65, "plain"), (3, 96, "plain")])
+def test_attention_d512_vs_fp64(b, n, kind, d512_variant, variant):
     """Both entry points against the fp64 definition on the 16-bit inputs: ragged tails, a batch, logits of +-150 and a
     late key that moves the running maximum; strided (fused q|k|v buffer) views as the VAE block passes them."""
+    d512_variant(variant)
     g = torch.Generator(device="cpu").manual_seed(n)
     q, k, v = (torch.randn(b, n, 512, generator=g) for _ in range(3))
     if kind == "wide":
