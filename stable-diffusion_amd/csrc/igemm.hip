@@ -828,6 +828,192 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
                               (brow + wr * TM) / 32, (bcol + wc * TN) / 32);
 }
 
+// ------------------------------------------------------------------------------------------ persistent plain GEMM
+// igemm_kernel pays its fixed part - block launch, argument loads, pointer set-up, the first K-tile's memory round trip,
+// the epilogue's stores - once per output tile; on the short-K GEMMs of the transformer blocks (K = 320: five K-tiles)
+// that is half a block's life, and a launch of several rounds of blocks (the GEGLU projection: 1440 tiles on 512 slots)
+// pays it every round.  Here a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the staging ring does not
+// stop at a tile's end: while tile i's last K-tiles are multiplied and its epilogue runs, the first NSTAGE K-tiles of
+// tile i+1 are already on their way.  Same K order, same epilogue: same bits as igemm_kernel.  No split-K, no conv.
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool GEGLU>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) * BK * 2 <= 80 * 1024 ? 2 : 1)) void igemm_persist_kernel(const IgemmParams p) {
+  constexpr int NTH = 64 * WM * WN, RP = NTH / 8;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 16, NT = TN / 16, PA = BM / RP, PB = BN / RP;
+  static_assert(BM % RP == 0 && BN % RP == 0 && TM % 16 == 0 && TN % 16 == 0, "tile / wave grid mismatch");
+  constexpr int STAGE = (BM + BN) * BK;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv / WN, wc = wv % WN, l15 = lane & 15, lq = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntile = tiles_m * tiles_n;
+  const int bz = blockIdx.y;
+  const u16* A = p.a + (long long)bz * p.sa;
+  const u16* Wp = p.w + (long long)bz * p.sw;
+  const u16* const zp = (const u16*)g_zero16;
+  const int r0 = t >> 3;
+  const int lchunk = (t & 7) ^ ((r0 >> 1) & 7);
+  const int wave_row0 = __builtin_amdgcn_readfirstlane(wv) * 8;
+  const int k_lim = p.K - lchunk * 8;
+  const int nk = p.nk;
+
+  // ---- staging cursor: the tile whose K-tiles are being fetched (runs NSTAGE K-tiles ahead of the multiplication) ----
+  const u16* a_ptr[PA];
+  bool a_ok[PA];
+  const u16* b_ptr[PB];
+  bool b_ok[PB];
+  int st_tile = blockIdx.x, s_k = 0;
+  bool s_live = st_tile < ntile;
+  auto set_ptrs = [&](int tile) {
+    const int bid = xcd_remap(tile, ntile);
+    const int brow = (p.nmajor ? bid % tiles_m : bid / tiles_n) * BM, bcol = (p.nmajor ? bid / tiles_m : bid % tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int gm = brow + r0 + RP * i;
+      a_ok[i] = gm < p.M;
+      a_ptr[i] = A + (long long)(a_ok[i] ? gm : 0) * p.lda + lchunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int gn = bcol + r0 + RP * i;
+      b_ok[i] = gn < p.N;
+      b_ptr[i] = Wp + (long long)(b_ok[i] ? gn : 0) * p.ldw + lchunk * 8;
+    }
+  };
+  if (s_live) set_ptrs(st_tile);
+#define PGEMM_GLDS(SRC, DST) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+  // always PA + PB DMA instructions per wave (the zero page past the last tile), so the counted waits are constants
+#define PGEMM_STAGE_NEXT(SLOT)                                                                \
+  {                                                                                           \
+    if (s_k == nk) {                                                                          \
+      st_tile += gridDim.x;                                                                   \
+      s_live = st_tile < ntile;                                                               \
+      if (s_live) set_ptrs(st_tile);                                                          \
+      s_k = 0;                                                                                \
+    }                                                                                         \
+    u16* dA = smem + (SLOT) * STAGE + wave_row0 * BK;                                         \
+    u16* dB = dA + BM * BK;                                                                   \
+    const int ko = s_k * BK;                                                                  \
+    const bool kok = s_live && ko < k_lim;                                                    \
+    _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                          \
+      const u16* src = (a_ok[i] && kok) ? a_ptr[i] + ko : zp;                                 \
+      PGEMM_GLDS(src, dA + i * RP * BK);                                                      \
+    }                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                          \
+      const u16* src = (b_ok[i] && kok) ? b_ptr[i] + ko : zp;                                 \
+      PGEMM_GLDS(src, dB + i * RP * BK);                                                      \
+    }                                                                                         \
+    ++s_k;                                                                                    \
+  }
+#define PGEMM_WAIT_STAGE(GROUPS)                                                                    \
+  {                                                                                                 \
+    constexpr int INFLIGHT = (GROUPS) * (PA + PB);                                                  \
+    static_assert(INFLIGHT >= 0 && INFLIGHT < 64, "vmcnt is a 6-bit counter");                     \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");                      \
+    __builtin_amdgcn_s_barrier();                                                                   \
+  }
+#define PGEMM_READ_FRAGS(AF, WF, SLOT, KK)                                                                       \
+  {                                                                                                              \
+    const u16* cA = smem + (SLOT) * STAGE;                                                                       \
+    const u16* cB = cA + BM * BK;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) AF[i] = *(const hx8*)&cA[lds_off(wr * TM + i * 16 + l15, lq + 4 * (KK))]; \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const hx8*)&cB[lds_off(wc * TN + j * 16 + l15, lq + 4 * (KK))]; \
+  }
+#define PGEMM_MFMA_ALL(AF, WF)                                                                 \
+  {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                             \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(WF[j], AF[i], acc[i][j], 0, 0, 0); \
+  }
+#pragma unroll
+  for (int sidx = 0; sidx < NSTAGE; ++sidx) PGEMM_STAGE_NEXT(sidx);
+
+  constexpr bool FAST_OK = !GEGLU || TN >= 64;
+  const bool fast = FAST_OK && p.fast_epi;
+  float* const lnside = (float*)(smem + NSTAGE * STAGE);
+  int slot = 0;
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int bid = xcd_remap(tile, ntile);
+    const int brow = (p.nmajor ? bid % tiles_m : bid / tiles_n) * BM, bcol = (p.nmajor ? bid / tiles_m : bid % tiles_n) * BN;
+    if (tile != (int)blockIdx.x) {
+      // the previous tile's stores are out and its reads of the LayerNorm side region are done before anything of this tile
+      // is counted or written: loads and stores do not retire in one order, so the counted waits below must not see stores
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    hx8 af0[MT], wf0[NT], af1[MT], wf1[NT];
+    EpiRegs<TM, FAST_OK ? TN : 64, GEGLU> er;
+    if constexpr (FAST_OK) if (fast) epi_prefetch<TM, TN, GEGLU>(p, er, bz, brow + wr * TM, bcol + wc * TN, lane);
+    if (p.ln_stats) {
+      {
+        constexpr int TPR = NTH / BM;
+        const int lrow = t / TPR, sub = t % TPR;
+        const int row = min(brow + lrow, p.M - 1);
+        const float2* sp = (const float2*)p.ln_stats + (long long)row * p.ln_parts;
+        constexpr int NA = 4 / TPR;
+        static_assert(TPR == 2 || TPR == 4, "two or four threads per tile row");
+        float a0[NA], a1[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) a0[j] = a1[j] = 0.f;
+        constexpr int ROUNDS = 6;
+        for (int pp = 0; pp < p.ln_parts; pp += 4 * ROUNDS) {
+          float2 v[ROUNDS][NA];
+#pragma unroll
+          for (int rr = 0; rr < ROUNDS; ++rr)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+              const int q = pp + 4 * rr + sub + j * TPR;
+              v[rr][j] = q < p.ln_parts ? sp[q] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+          for (int rr = 0; rr < ROUNDS; ++rr)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) { a0[j] += v[rr][j].x; a1[j] += v[rr][j].y; }
+        }
+        float s0, s1;
+        if constexpr (TPR == 4) {
+          s0 = a0[0] + __shfl_xor(a0[0], 1); s1 = a1[0] + __shfl_xor(a1[0], 1);
+          s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
+        } else {
+          const float b0 = a0[0] + __shfl_xor(a0[0], 1), b1 = a1[0] + __shfl_xor(a1[0], 1);
+          const float c0 = a0[1] + __shfl_xor(a0[1], 1), c1 = a1[1] + __shfl_xor(a1[1], 1);
+          s0 = b0 + c0; s1 = b1 + c1;
+        }
+        if (sub == 0) {
+          const float inv = 1.0f / (float)p.K;
+          const float mean = s0 * inv;
+          const float var = fmaxf(s1 * inv - mean * mean, 0.f);
+          ((float2*)lnside)[lrow] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+        }
+      }
+      for (int c = t; c < BN; c += NTH) lnside[2 * BM + c] = bcol + c < p.N ? p.ln_u[bcol + c] : 0.f;
+    }
+    PGEMM_WAIT_STAGE(NSTAGE - 1);
+    PGEMM_READ_FRAGS(af0, wf0, slot, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+      PGEMM_READ_FRAGS(af1, wf1, slot, 1);
+      PGEMM_MFMA_ALL(af0, wf0);
+      PGEMM_WAIT_STAGE(NSTAGE - 2);
+      PGEMM_STAGE_NEXT(slot);
+      PGEMM_READ_FRAGS(af0, wf0, nslot, 0);
+      PGEMM_MFMA_ALL(af1, wf1);
+      slot = nslot;
+    }
+    igemm_finish<TM, TN, GEGLU, true, true>(p, acc, er, fast, smem, bz, brow + wr * TM, bcol + wc * TN, (lds_cfp)lnside, BM, wr * TM, wc * TN,
+                                            (brow + wr * TM) / 32, (bcol + wc * TN) / 32);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef PGEMM_GLDS
+#undef PGEMM_STAGE_NEXT
+#undef PGEMM_WAIT_STAGE
+#undef PGEMM_READ_FRAGS
+#undef PGEMM_MFMA_ALL
+}
+
 // ------------------------------------------------------------------------------------------ shared-window 3x3 conv
 // Stride-1, pad-1 convolutions.  The generic kernel stages a fresh 128 x 64 activation tile for each of the 9 taps; the
 // three taps of one kernel row (kx = 0, 1, 2) read the SAME pixels shifted by one, so here ONE window of BM + 2 pixel
@@ -1137,6 +1323,36 @@ static void launch_variant(dim3 grid, hipStream_t st, const IgemmParams& p) {
   launch_variant2<BM, BN, WM, WN, CONV, NSTAGE, false>(grid, st, p);
 }
 
+// persistent launch (igemm_persist_kernel): `slots` blocks walk the nb tiles
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool GEGLU>
+static void launch_persist2(int slots, int batch, hipStream_t st, const IgemmParams& p) {
+  constexpr int ring = NSTAGE * (BM + BN) * BK * 2;
+  constexpr int bytes = ring + BM * 8 + BN * 4;
+  auto kfn = igemm_persist_kernel<BM, BN, WM, WN, NSTAGE, GEGLU>;
+  static unsigned long long attr_done = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (bytes > 65536 && !((attr_done >> (dev & 63)) & 1ull)) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    attr_done |= 1ull << (dev & 63);
+  }
+  hipLaunchKernelGGL(kfn, dim3(slots, batch, 1), dim3(64 * WM * WN), p.ln_stats ? bytes : ring, st, p);
+}
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+static void launch_persist(int slots, int batch, hipStream_t st, const IgemmParams& p) {
+  if constexpr ((BN / WN) % 32 == 0) {
+    if (p.flags & SDMI_F_GEGLU) { launch_persist2<BM, BN, WM, WN, NSTAGE, true>(slots, batch, st, p); return; }
+  }
+  launch_persist2<BM, BN, WM, WN, NSTAGE, false>(slots, batch, st, p);
+}
+// blocks of a tile variant one CU holds (LDS; the 4-wave tiles run at 2 waves per SIMD or more)
+static int variant_blocks_per_cu(const TileVariant& tv, bool ln) {
+  const int bytes = tv.nstage * (tv.bm + tv.bn) * BK * 2 + (ln ? tv.bm * 8 + tv.bn * 4 : 0);
+  int n = (160 * 1024) / bytes;
+  if (tv.wm * tv.wn == 8) n = n > 1 ? 1 : n;
+  return n > 2 ? 2 : (n < 1 ? 1 : n);
+}
+
 // Tile choice.  The main loop is bound by the L2 -> LDS path (about 70 GB/s per CU), so the biggest tile that still
 // gives every CU a block wins; SDMI_IGEMM_TILE=<index into kVariants> forces one (experiments).
 static int choose_variant(const IgemmParams& p, int batch, bool conv) {
@@ -1296,6 +1512,31 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
       if (split_colstats) hipLaunchKernelGGL(igemm_splitk_reduce_stats_kernel, dim3((unsigned)((p.M / 32) * ((p.N + 31) / 32))), dim3(256), 0, st, p, split_colstats);
       else hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
       return sdmi_check_launch("split-K reduce");
+    }
+  }
+  // Persistent blocks, the next tile's first K-tiles fetched under the current tile's tail and epilogue: an opt-in
+  // (gemm_persist: 0 off, 1 for launches of more tiles than resident blocks, 2 whenever the kernel can run the problem).
+  // Bit-identical to igemm_kernel and measured equal or slower on every GEMM of the UNet (profiles/r02_persist_gemm_ab.txt).
+  if constexpr (!CONV) {
+    const int popt = sdmi_option("gemm_persist");
+    if (popt != 0 && p.splits == 1 && vi >= 1 && vi <= 4 && p.nk >= tv.nstage && !(p.flags & SDMI_F_GEGLU && (tv.bn / tv.wn) % 32 != 0)) {
+      static int cus[64] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (!cus[dev & 63]) {
+        int n = 0;
+        cus[dev & 63] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+      }
+      const int slots = cus[dev & 63] * variant_blocks_per_cu(tv, p.ln_stats != nullptr);
+      if (popt == 2 || (long long)nb * batch > slots) {
+        const int gx = nb < slots ? nb : (batch > 1 ? (slots / batch > 0 ? slots / batch : 1) : slots);
+        if (vi == 1) launch_persist<128, 128, 2, 2, 2>(gx, batch, st, p);
+        else if (vi == 2) launch_persist<128, 64, 2, 2, 2>(gx, batch, st, p);
+        else if (vi == 3) launch_persist<64, 128, 2, 2, 3>(gx, batch, st, p);
+        else launch_persist<64, 64, 2, 2, 3>(gx, batch, st, p);
+        sdmi_note_kernel("igemm_persist_kernel<%d, %d, %d, %d, %d, %s>", bm, bn, tv.wm, tv.wn, tv.nstage, (p.flags & SDMI_F_GEGLU) ? "true" : "false");
+        return sdmi_check_launch("gemm");
+      }
     }
   }
   switch (vi) {

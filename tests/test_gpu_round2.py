@@ -715,3 +715,47 @@ def test_splitk_conv_leaves_column_statistics():
     g1 = E.groupnorm(y1, gamma, beta, 1e-5, silu=True).buf.float()
     g0 = E.groupnorm(y0, gamma, beta, 1e-5, silu=True).buf.float()
     assert float((g1 - g0).norm() / g0.norm()) < 6e-4 * _tol()
+
+
+# ------------------------------------------------------------------ persistent-block GEMM (opt-in): same bits as igemm_kernel
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k,kind", [
+    (9216, 960, 320, "ln"),          # more tiles than resident blocks: blocks walk two tiles, LayerNorm side data per tile
+    (4608, 640, 640, "res"),
+    (1000, 200, 328, "res"),         # ragged rows, columns and K (the last K-tile is partly the zero page)
+    (2304, 2560, 320, "geglu"),
+    (70, 64, 192, "res"),            # a single tile, three K-tiles: ring as deep as the K loop
+])
+def test_persistent_gemm_bit_identical_to_tile_per_block(m, n, k, kind):
+    """igemm_persist_kernel (sdmi_set_option gemm_persist = 2) keeps K order and epilogue of igemm_kernel: equal bits, the
+    row statistics it leaves included.  Off by default (profiles/r02_persist_gemm_ab.txt)."""
+    dev = torch.device("cuda", 0)
+    lib = L.load()
+    H = E.act_dtype()
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    a = E.Act(rnd(1, m, k).to(H), 1, 1, m, k)
+    w = (rnd(n, k) / k ** 0.5).to(H)
+    b = rnd(n)
+    kw = {}
+    if kind == "ln":
+        a = E.gemm(a, (rnd(k, k) / k ** 0.5).to(H), k, bias=rnd(k), rowstats=True)
+        assert a.rstats is not None
+        kw = dict(ln=(rnd(n), 1e-5))
+    if kind == "res":
+        kw = dict(residual=E.Act(rnd(1, m, n).to(H), 1, 1, m, n), rowstats=True)
+    outs = []
+    try:
+        for opt in (0, 2):
+            lib.sdmi_set_option(b"gemm_persist", opt)
+            r = E.gemm(a, w, n, bias=b, geglu=(kind == "geglu"), **kw)
+            name = lib.sdmi_last_kernel().decode()
+            assert name.startswith("igemm_persist_kernel" if opt else "igemm_kernel"), name
+            outs.append((r.buf.clone(), None if r.rstats is None else r.rstats[0].clone()))
+    finally:
+        lib.sdmi_set_option(b"gemm_persist", 0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert (outs[0][1] is None) == (outs[1][1] is None)
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[1][0].float()).all()
