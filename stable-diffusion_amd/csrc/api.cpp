@@ -52,7 +52,7 @@ static struct { const char* name; int value; } g_options[] = {
     {"bm128_min", 0},           // > 0: 128-row tiles once they number at least this (default 128)
     {"gemm_t2_min_blocks", 0},  // > 0: plain GEMMs take 128 x 64 tiles once those number at least this (default 360; round 1: 600)
     {"split_colstats_off", 0},  // 1: split-K launches leave no column statistics (A/B switch)
-    {"gemm_persist", 0},        // persistent GEMM blocks (igemm_persist_kernel): 0 off, 1 when a launch has more tiles than resident blocks, 2 always
+    {"gemm_persist", 0},        // persistent GEMM blocks (igemm_persist_kernel): 0 off, 1 when a launch has more tiles than resident blocks, 2 always, 3 as 1 for GEGLU GEMMs only
     {"attn_d512_variant", 0},   // d = 512 attention: 0 automatic (8-wave kernel), 1 the 4-wave kernel, 2 the 8-wave kernel
     {"gemm_small_m_tile", 1},   // 1: 64x64 tiles for K >= 2048 GEMMs with fewer than 1024 rows (0: 64x128 as in round 1)
     {"attn_x2_min_nq", 0},      // > 0: query rows from which long self-attention takes the 64-rows-per-wave kernel (default 2048)

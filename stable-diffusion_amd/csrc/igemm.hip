@@ -1515,7 +1515,8 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     }
   }
   // Persistent blocks, the next tile's first K-tiles fetched under the current tile's tail and epilogue: an opt-in
-  // (gemm_persist: 0 off, 1 for launches of more tiles than resident blocks, 2 whenever the kernel can run the problem).
+  // (gemm_persist: 0 off, 1 for launches of more tiles than resident blocks, 2 whenever the kernel can run the problem,
+  // 3 as 1 but GEGLU GEMMs only).
   // Bit-identical to igemm_kernel and measured equal or slower on every GEMM of the UNet (profiles/r02_persist_gemm_ab.txt).
   if constexpr (!CONV) {
     const int popt = sdmi_option("gemm_persist");
@@ -1528,7 +1529,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         cus[dev & 63] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
       }
       const int slots = cus[dev & 63] * variant_blocks_per_cu(tv, p.ln_stats != nullptr);
-      if (popt == 2 || (long long)nb * batch > slots) {
+      if (popt == 2 || ((long long)nb * batch > slots && (popt != 3 || (p.flags & SDMI_F_GEGLU)))) {
         const int gx = nb < slots ? nb : (batch > 1 ? (slots / batch > 0 ? slots / batch : 1) : slots);
         if (vi == 1) launch_persist<128, 128, 2, 2, 2>(gx, batch, st, p);
         else if (vi == 2) launch_persist<128, 64, 2, 2, 2>(gx, batch, st, p);
