@@ -175,7 +175,9 @@ class Sampler(object):
             self._unet_eval(xc, t_buf, cc, same_halves)         # warm-up: weight pre-pack, allocator pools
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: only this thread's calls are checked during capture; another thread's (the RCCL watchdog of a
+            # multi-GPU run polling its events) must not invalidate it
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self._unet_eval(xc, t_buf, cc, same_halves)
             self._graph, self._gout, self._gkey, self._gkeep = g, out, key, (xc, t_buf, cc)
         self._graph.replay()
@@ -241,7 +243,7 @@ class Sampler(object):
             self.vae.decode_image_u8(1. / SCALE_FACTOR * self._din)     # warm-up: weight pre-pack, allocator pools
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self.vae.decode_image_u8(1. / SCALE_FACTOR * self._din)
             self._dgraph, self._dout, self._dkey = g, out, key
         self._din.copy_(latent)
