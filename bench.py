@@ -123,7 +123,10 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SDMI_BENCH_FORCE_DIST=1: a one-rank launch still goes through the RCCL group (rehearsal of the N > 1 control flow
+    # on a one-GPU box: barriers, the MAX all-reduce of the time, the image all-gather, rank 0's roofline pass)
+    use_dist = world > 1 or os.environ.get("SDMI_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     _lib.load()
@@ -161,7 +164,7 @@ def main():
         return all_gather_images(img, total)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -174,7 +177,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     assert out.shape[0] == total and out.dtype == torch.uint8
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -340,7 +343,7 @@ def main():
                             "the same pass: profiles/r02_roofline_pass_kernel_stats.csv)" % (2 * b, args.ddim_steps),
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()   # rank 0 runs the roofline pass after the timed region: keep the group alive until it is done
         dist.destroy_process_group()
 
