@@ -58,8 +58,6 @@ def work_of(name, a):
         return 0.0, 4.0 * a[5] * a[6] * a[7]
     if name == "sdmi_layernorm":
         return 0.0, 4.0 * a[7] * a[8]
-    if name == "sdmi_softmax_rows":
-        return 0.0, 6.0 * a[4] * a[5]
     return 0.0, 0.0
 
 

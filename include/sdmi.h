@@ -81,10 +81,14 @@ int sdmi_groupnorm(const void* x, int ldx, void* y, int ldy, int n, int hw, int 
  *      Same arithmetic and bits as sdmi_groupnorm; the scale/shift table and the partial sums live in a static device
  *      array of sdmi_groupnorm_static_max_bytes() (1 MiB) per GPU instead of caller-provided buffers.  Shapes that need
  *      more (n*c*8 rounded up to 256 + sdmi_groupnorm_ws_bytes(n, hw, c) bytes) are rejected with SDMI_EINVAL.  Calls on
- *      one GPU share that array: calls that overlap in time on one GPU (different streams) race. */
+ *      one GPU share that array: calls that overlap in time on one GPU (different streams) race.  The array's address is
+ *      looked up once per device (hipGetSymbolAddress, not a capturable operation): sdmi_groupnorm_static_init() does that
+ *      for the current device; the first sdmi_groupnorm_static call on a device does it too unless `stream` is capturing,
+ *      in which case it fails with SDMI_EINVAL instead of breaking the capture.  `stream` must belong to the current device. */
 int sdmi_groupnorm_static(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups, const float* gamma,
                           const float* beta, float eps, uint32_t flags, void* stream);
 int64_t sdmi_groupnorm_static_max_bytes(void);
+int sdmi_groupnorm_static_init(void);
 
 /* ---- LayerNorm: nn.LayerNorm at layers/SpatialTransformer.py:177-184 ----------------------- */
 int sdmi_layernorm(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
@@ -252,10 +256,6 @@ int sdmi_attention_causal(const void* q, int ldq, int64_t sq, const void* k, int
 int sdmi_embed_tokens(const int64_t* tokens, const float* table, const float* pos, void* out, int rows, int seq_len, int width,
                       int vocab, int ldo, void* stream);
 int sdmi_gelu_rows(void* x, int ldx, int rows, int cols, void* stream);
-
-/* ---- row softmax (VAE single-head d=512 attention, layers/SpatialTransformer.py:151, runs as
- *      score GEMM -> this -> value GEMM).  x fp32 [rows][ldx] -> y bf16 [rows][ldy], y = softmax(x*scale). */
-int sdmi_softmax_rows(const float* x, int ldx, void* y, int ldy, int rows, int cols, float scale, void* stream);
 
 /* ---- inpainting pre-processing: pad_image + make_batch_sd + the mask branch of inpaint()'s c_cat loop
  *      (LatentDiffusionInpainting.py:58-63, :65-89, :281-285) in one pass.  image uint8 HWC (h0, w0, 3); mask uint8

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "sdmi_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _u32, _vp, _vp, _vp]),
     "sdmi_groupnorm_static": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _u32, _vp]),
     "sdmi_groupnorm_static_max_bytes": (_i64, []),
+    "sdmi_groupnorm_static_init": (_i, []),
     "sdmi_layernorm": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "sdmi_conv3x3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp, _i64, _vp]),
     "sdmi_conv3x3_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
@@ -72,7 +73,6 @@ PROTOTYPES = {
     "sdmi_ws_tickets_init": (_i, [_vp, _vp]),
     "sdmi_ws_tickets_release": (_i, [_vp]),
     "sdmi_attention_log2q": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
-    "sdmi_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "sdmi_cfg_ddim_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -39,33 +39,23 @@ extern "C" int sdmi_act_dtype(void) { return 0; }
 #endif
 extern "C" const char* sdmi_last_error(void) { return g_err; }
 
-// Runtime experiment switches (benchmarks / A-B runs only; defaults are the shipped behaviour).  A tiny name -> int table
-// read by the launch paths: lets one process time two code paths interleaved (scratch/ab_step.py) instead of comparing
-// runs on different boxes.
+// Runtime experiment switches (benchmarks / A-B runs only; defaults are the shipped behaviour): lets one process time two
+// code paths interleaved (scratch/ab_step.py) instead of comparing runs on different boxes.  Table: common.h SDMI_OPTIONS.
 #include <string.h>
-static struct { const char* name; int value; } g_options[] = {
-    {"conv_nmajor_by_rows", 0}, // 1: conv tile order by N > M as in round 1 (0: by operand bytes, 9 N > M)
-    {"splitk_target", 0},       // > 0: blocks a split-K launch aims for per sample (default 512; round 1: 384)
-    {"splitk_max_tiles", 0},    // > 0: split K only when a sample has at most this many tiles (default 256; round 1: 128)
-    {"splitk_min_kt_conv", 0},  // > 0: K-tiles (of 64) a conv split keeps at least (default 16)
-    {"splitk_min_kt_gemm", 0},  // > 0: same for plain GEMMs (default 24; round 1: 32)
-    {"bm128_min", 0},           // > 0: 128-row tiles once they number at least this (default 128)
-    {"gemm_t2_min_blocks", 0},  // > 0: plain GEMMs take 128 x 64 tiles once those number at least this (default 360; round 1: 600)
-    {"split_colstats_off", 0},  // 1: split-K launches leave no column statistics (A/B switch)
-    {"gemm_persist", 0},        // persistent GEMM blocks (igemm_persist_kernel): 0 off, 1 when a launch has more tiles than resident blocks, 2 always, 3 as 1 for GEGLU GEMMs only
-    {"attn_d512_variant", 0},   // d = 512 attention: 0 automatic (8-wave kernel), 1 the 4-wave kernel, 2 the 8-wave kernel
-    {"gemm_small_m_tile", 1},   // 1: 64x64 tiles for K >= 2048 GEMMs with fewer than 1024 rows (0: 64x128 as in round 1)
-    {"attn_x2_min_nq", 0},      // > 0: query rows from which long self-attention takes the 64-rows-per-wave kernel (default 2048)
-    {"attn_variant", 0},        // attention kernel variant (0 = default)
+#include "common.h"
+int g_sdmi_opt[OPT_COUNT] = {
+#define SDMI_OPT_DEF(name, def, doc) def,
+    SDMI_OPTIONS(SDMI_OPT_DEF)
+#undef SDMI_OPT_DEF
 };
-int sdmi_option(const char* name) {
-  for (auto& o : g_options)
-    if (!strcmp(o.name, name)) return o.value;
-  return 0;
-}
+static const char* const g_opt_names[OPT_COUNT] = {
+#define SDMI_OPT_NAME(name, def, doc) #name,
+    SDMI_OPTIONS(SDMI_OPT_NAME)
+#undef SDMI_OPT_NAME
+};
 extern "C" int sdmi_set_option(const char* name, int value) {
-  for (auto& o : g_options)
-    if (!strcmp(o.name, name)) { o.value = value; return SDMI_OK; }
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (!strcmp(g_opt_names[i], name)) { g_sdmi_opt[i] = value; return SDMI_OK; }
   sdmi_set_error("sdmi_set_option: unknown option '%s'", name);
   return SDMI_EINVAL;
 }

@@ -508,8 +508,8 @@ static int attention_launch(const void* q, int ldq, int64_t sq, const void* k, i
   p.sq = sq; p.sk = sk; p.sv = sv; p.so = so; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.nq = nq; p.nkv = nkv; p.scale_log2 = log2q ? 1.0f : scale * 1.44269504088896340736f;
   // long self-attention: the 64-rows-per-wave structure (attn_variant: -1 never, 1 always, 0 = by shape)
-  const int variant = sdmi_option("attn_variant");
-  const int min_nq = sdmi_option("attn_x2_min_nq");
+  const int variant = sdmi_opt(OPT_attn_variant);
+  const int min_nq = sdmi_opt(OPT_attn_x2_min_nq);
   if (variant > 0 || (variant == 0 && nkv >= 1024 && nq >= (min_nq > 0 ? min_nq : 2048))) {
     p.nqt = (nq + 127) / 128; p.heads = heads;
     hipLaunchKernelGGL(attn64x2_kernel, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);

@@ -396,7 +396,7 @@ static int attention_d512_launch(const void* q, int ldq, int64_t sq, const void*
     attr_done |= 1ull << (dev & 63);
   }
   // attn_d512_variant: 0 = automatic (the 8-wave kernel), 1 = the 4-wave kernel, 2 = the 8-wave kernel (A/B switch)
-  const int variant = sdmi_option("attn_d512_variant");
+  const int variant = sdmi_opt(OPT_attn_d512_variant);
   SDMI_REQUIRE(variant != 2 || w8_ok[dev & 63], "attention_d512: the 8-wave kernel needs %d bytes of LDS per block", lds_bytes_w8);
   if (variant != 1 && w8_ok[dev & 63]) {
     p.nqt = (n + 63) / 64;

@@ -34,7 +34,30 @@ typedef h16 hx2 __attribute__((ext_vector_type(2)));
 void sdmi_set_error(const char* fmt, ...);
 int sdmi_check_launch(const char* what);
 void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the last entry point launched
-int sdmi_option(const char* name);           // runtime experiment switch (api.cpp; sdmi_set_option)
+// Runtime experiment switches (api.cpp; sdmi_set_option by name).  The launch paths read them by integer id: an array
+// load, not a string search, on every launch.  X(name, default, meaning)
+#define SDMI_OPTIONS(X)                                                                                                                       \
+  X(conv_nmajor_by_rows, 0, "1: conv tile order by N > M as in round 1 (0: by operand bytes, 9 N > M)")                                          \
+  X(splitk_target, 0, "> 0: blocks a split-K launch aims for per sample (default 512; round 1: 384)")                                            \
+  X(splitk_max_tiles, 0, "> 0: split K only when a sample has at most this many tiles (default 256; round 1: 128)")                              \
+  X(splitk_min_kt_conv, 0, "> 0: K-tiles (of 64) a conv split keeps at least (default 16)")                                                      \
+  X(splitk_min_kt_gemm, 0, "> 0: same for plain GEMMs (default 24; round 1: 32)")                                                                \
+  X(bm128_min, 0, "> 0: 128-row tiles once they number at least this (default 128)")                                                             \
+  X(gemm_t2_min_blocks, 0, "> 0: plain GEMMs take 128 x 64 tiles once those number at least this (default 360; round 1: 600)")                   \
+  X(split_colstats_off, 0, "1: split-K launches leave no column statistics (A/B switch)")                                                        \
+  X(gemm_persist, 0, "persistent GEMM blocks: 0 off, 1 when a launch has more tiles than resident blocks, 2 always, 3 as 1 for GEGLU only")      \
+  X(attn_d512_variant, 0, "d = 512 attention: 0 automatic (8-wave kernel), 1 the 4-wave kernel, 2 the 8-wave kernel")                            \
+  X(gemm_small_m_tile, 1, "1: 64x64 tiles for K >= 2048 GEMMs with fewer than 1024 rows (0: 64x128 as in round 1)")                              \
+  X(attn_x2_min_nq, 0, "> 0: query rows from which long self-attention takes the 64-rows-per-wave kernel (default 2048)")                        \
+  X(attn_variant, 0, "attention kernel variant (0 = default)")
+enum SdmiOpt {
+#define SDMI_OPT_ENUM(name, def, doc) OPT_##name,
+  SDMI_OPTIONS(SDMI_OPT_ENUM)
+#undef SDMI_OPT_ENUM
+  OPT_COUNT
+};
+extern int g_sdmi_opt[OPT_COUNT];
+static inline int sdmi_opt(SdmiOpt id) { return g_sdmi_opt[id]; }
 
 #define SDMI_REQUIRE(cond, ...)            \
   do {                                     \

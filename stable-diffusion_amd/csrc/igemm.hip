@@ -423,7 +423,8 @@ __device__ __forceinline__ void epi_finish(const IgemmParams& p, const EpiRegs<T
           for (int pr = 0; pr < R::NP; ++pr) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { csum[pr][e] = row16_sum(csum[pr][e]); csq[pr][e] = row16_sum(csq[pr][e]); }
-            if (l15 == 0 && cvalid[pr]) {
+            // (a wave tile that lies wholly past M - M a multiple of the wave tile but not of the block tile - has no part)
+            if (l15 == 0 && cvalid[pr] && (spart + (i >> 1)) * 32 < p.M) {
               float* o = p.colstats + ((long long)(spart + (i >> 1)) * p.N + ocol[pr]) * 2;
 #pragma unroll
               for (int e = 0; e < 8; e += 2) *(f32x4*)(o + 2 * e) = f32x4{csum[pr][e], csq[pr][e], csum[pr][e + 1], csq[pr][e + 1]};
@@ -794,10 +795,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
           s0 = b0 + c0; s1 = b1 + c1;
         }
         if (sub == 0) {
-          const float inv = 1.0f / (float)p.K;
-          const float mean = s0 * inv;
-          const float var = fmaxf(s1 * inv - mean * mean, 0.f);
-          ((float2*)lnside)[lrow] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+          // finished in double: E[x^2] - mean^2 cancels for rows whose |mean| is far above their spread
+          const double inv = 1.0 / (double)p.K;
+          const double mean = (double)s0 * inv;
+          const double var = fmax((double)s1 * inv - mean * mean, 0.0);
+          ((float2*)lnside)[lrow] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.ln_eps)));
         }
       }
       for (int c = t; c < BN; c += NTH) lnside[2 * BM + c] = bcol + c < p.N ? p.ln_u[bcol + c] : 0.f;
@@ -983,10 +985,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
           s0 = b0 + c0; s1 = b1 + c1;
         }
         if (sub == 0) {
-          const float inv = 1.0f / (float)p.K;
-          const float mean = s0 * inv;
-          const float var = fmaxf(s1 * inv - mean * mean, 0.f);
-          ((float2*)lnside)[lrow] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+          // finished in double: E[x^2] - mean^2 cancels for rows whose |mean| is far above their spread
+          const double inv = 1.0 / (double)p.K;
+          const double mean = (double)s0 * inv;
+          const double var = fmax((double)s1 * inv - mean * mean, 0.0);
+          ((float2*)lnside)[lrow] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.ln_eps)));
         }
       }
       for (int c = t; c < BN; c += NTH) lnside[2 * BM + c] = bcol + c < p.N ? p.ln_u[bcol + c] : 0.f;
@@ -1229,14 +1232,14 @@ static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags, boo
   const int bn = ((n % 128 == 0) || (n > 512)) ? 128 : 64;
   const int bm = rows_per_sample >= 1024 ? 128 : 64;
   const long long tiles = (long long)((rows_per_sample + bm - 1) / bm) * ((n + bn - 1) / bn);
-  const int opt_target = sdmi_option("splitk_target"), opt_max = sdmi_option("splitk_max_tiles");
+  const int opt_target = sdmi_opt(OPT_splitk_target), opt_max = sdmi_opt(OPT_splitk_max_tiles);
   if (tiles > (opt_max > 0 ? opt_max : 256)) return 1;
   long long s = (opt_target > 0 ? opt_target : target) / tiles;
   // at least 1024 of K per split (plain GEMMs: 1536), below that the fp32 round trip costs more than it buys (sweep of
   // the UNet's shapes, scratch/tune_sweep.py: K = 2560 GEMMs ran 25-35 % faster unsplit).  Round 2, with the two CFG
   // halves as concurrent batch-1 passes (scratch/ab_step.py, same-process A/B of the captured step): 512 blocks per
   // sample instead of 384 and splitting up to 256 tiles instead of 128 -1.3 %, GEMM splits from K = 3072 -0.5 %.
-  const int opt_kt = sdmi_option(conv ? "splitk_min_kt_conv" : "splitk_min_kt_gemm");
+  const int opt_kt = sdmi_opt(conv ? OPT_splitk_min_kt_conv : OPT_splitk_min_kt_gemm);
   const int min_kt = opt_kt > 0 ? opt_kt : (conv ? 16 : 24);
   if (s > nk / min_kt) s = nk / min_kt;
   if (s > 16) s = 16;
@@ -1370,12 +1373,12 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
     // than two 128x128 ones; grids too small for that run the smallest tile, except long-K wide-N ones (weights are the
     // traffic there).  From the sweep of the UNet's shapes, scratch/tune_sweep.py.
     const long long b2 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * batch * p.splits;
-    const int t2_min = sdmi_option("gemm_t2_min_blocks");
+    const int t2_min = sdmi_opt(OPT_gemm_t2_min_blocks);
     // (round 2, two concurrent batch-1 passes: 360 instead of 600 - the 9216 x 320 GEMMs of one CFG half - step -1.1 %)
     if (b2 >= (t2_min > 0 ? t2_min : 360)) return 2;
     // (64 x 128 only with enough rows: at M = 576 / 144, one CFG half of the 24x24 / 12x12 levels, 64 x 64 ran 1.1 - 1.6x
     // faster on the K >= 2048 GEMMs: scratch/gemm_sweep_b1.py)
-    if (p.K >= 2048 && p.N >= 1024 && (p.M >= 1024 || !sdmi_option("gemm_small_m_tile"))) return 3;
+    if (p.K >= 2048 && p.N >= 1024 && (p.M >= 1024 || !sdmi_opt(OPT_gemm_small_m_tile))) return 3;
     return 4;
   }
   if (!conv && p.M <= 256) return 3;  // GEGLU on a 12x12 level: 64-row tiles (144 rows in 128-row tiles compute 256)
@@ -1386,7 +1389,7 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   // the two CFG halves as concurrent batch-1 passes, so the other half of the chip is not idle (256 -> 128: +3.3 %
   // images/s at 768x768; SDMI_BM128_MIN overrides)
   static const int bm128_min = [] { const char* e = getenv("SDMI_BM128_MIN"); return e ? atoi(e) : 128; }();
-  const int opt_bm = sdmi_option("bm128_min");
+  const int opt_bm = sdmi_opt(OPT_bm128_min);
   const bool bm128 = p.M > 64 && tiles128 >= (opt_bm > 0 ? opt_bm : bm128_min);
   if (bm128 && bn128) return 1;
   if (bm128) return 2;
@@ -1417,7 +1420,7 @@ static void stats_parts_of(const IgemmParams& p, int batch, int vi, int* row_par
   const bool plain = p.splits == 1 && batch == 1 && p.N % 8 == 0 &&
                      !(p.flags & (SDMI_F_GEGLU | SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE | SDMI_F_OUT_F32)) && tn >= 32 && tm >= 32;
   // a split-K launch leaves the column statistics from its reduce kernel (igemm_splitk_reduce_stats_kernel)
-  const bool split_cs = p.splits > 1 && batch == 1 && p.N % 4 == 0 && p.M % 32 == 0 && !sdmi_option("split_colstats_off") &&
+  const bool split_cs = p.splits > 1 && batch == 1 && p.N % 4 == 0 && p.M % 32 == 0 && !sdmi_opt(OPT_split_colstats_off) &&
                         !(p.flags & (SDMI_F_GEGLU | SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE | SDMI_F_OUT_F32));
   if (row_parts) *row_parts = (((plain && p.M % tm == 0) || split_cs) && p.rows_per_sample % 32 == 0) ? p.M / 32 : 0;
   if (col_parts) *col_parts = (plain && p.N % 32 == 0) ? p.N / 32 : 0;
@@ -1468,7 +1471,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     if (force == -2) { const char* e = getenv("SDMI_NMAJOR"); force = e ? atoi(e) : -1; }
     // bytes of the two operands: weights N x K against activations M x K (GEMM) or M x Cin (conv: K = 9 Cin, the window
     // of a row tile is fetched once per tile)
-    const long long wpanel = (long long)p.N * p.K, apanel = (long long)p.M * (CONV && !sdmi_option("conv_nmajor_by_rows") ? p.K / 9 : p.K);
+    const long long wpanel = (long long)p.N * p.K, apanel = (long long)p.M * (CONV && !sdmi_opt(OPT_conv_nmajor_by_rows) ? p.K / 9 : p.K);
     p.nmajor = force >= 0 ? force : (wpanel > apanel ? 1 : 0);
   }
   // SDMI_F_WS_TICKETS (opt-in): the block that draws a tile's last ticket sums the partials in split order and runs the
@@ -1519,7 +1522,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   // 3 as 1 but GEGLU GEMMs only).
   // Bit-identical to igemm_kernel and measured equal or slower on every GEMM of the UNet (profiles/r02_persist_gemm_ab.txt).
   if constexpr (!CONV) {
-    const int popt = sdmi_option("gemm_persist");
+    const int popt = sdmi_opt(OPT_gemm_persist);
     if (popt != 0 && p.splits == 1 && vi >= 1 && vi <= 4 && p.nk >= tv.nstage && !(p.flags & SDMI_F_GEGLU && (tv.bn / tv.wn) % 32 != 0)) {
       static int cus[64] = {};
       int dev = 0;

@@ -599,23 +599,31 @@ extern "C" int sdmi_groupnorm_from_colstats(const void* x, int ldx, void* y, int
 constexpr size_t GN_STATIC_BYTES = 1u << 20;
 static __device__ __align__(256) unsigned char scratch[GN_STATIC_BYTES];
 
-static unsigned char* gn_static_ptr() {
-  static unsigned char* ptr_of_device[64] = {};
+static unsigned char* g_gn_static_ptr[64] = {};  // per device: the array's address on that GPU
+static int gn_static_device() {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
     sdmi_set_error("groupnorm_static: hipGetDevice failed or device index %d >= 64", dev);
-    return nullptr;
+    return -1;
   }
-  if (!ptr_of_device[dev]) {
+  return dev;
+}
+// Resolve the array's address on the CURRENT device (once per device).  hipGetSymbolAddress is not a stream operation and
+// may load the code object: it must not run while a stream of this thread is capturing, so callers that capture call
+// this (or one eager sdmi_groupnorm_static) first.
+extern "C" int sdmi_groupnorm_static_init(void) {
+  const int dev = gn_static_device();
+  if (dev < 0) return SDMI_ELAUNCH;
+  if (!g_gn_static_ptr[dev]) {
     void* ptr = nullptr;
     const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !ptr) {
       sdmi_set_error("groupnorm_static: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
-      return nullptr;
+      return SDMI_ELAUNCH;
     }
-    ptr_of_device[dev] = (unsigned char*)ptr;
+    g_gn_static_ptr[dev] = (unsigned char*)ptr;
   }
-  return ptr_of_device[dev];
+  return SDMI_OK;
 }
 
 extern "C" int64_t sdmi_groupnorm_static_max_bytes(void) { return (int64_t)GN_STATIC_BYTES; }
@@ -628,8 +636,20 @@ extern "C" int sdmi_groupnorm_static(const void* x, int ldx, void* y, int ldy, i
   SDMI_REQUIRE(need <= (int64_t)GN_STATIC_BYTES,
                "groupnorm_static: n=%d hw=%d c=%d needs %lld bytes of scratch, the static buffer holds %lld: use sdmi_groupnorm "
                "with caller-allocated buffers", n, hw, c, (long long)need, (long long)GN_STATIC_BYTES);
-  unsigned char* ptr = gn_static_ptr();
-  if (!ptr) return SDMI_ELAUNCH;
+  // the array of the CURRENT device: `stream` must belong to it (a launch on another device's stream fails in HIP)
+  const int dev = gn_static_device();
+  if (dev < 0) return SDMI_ELAUNCH;
+  if (!g_gn_static_ptr[dev]) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      sdmi_set_error("groupnorm_static: first call on device %d is under stream capture; call sdmi_groupnorm_static_init() "
+                     "(or run one call eagerly) before capturing", dev);
+      return SDMI_EINVAL;
+    }
+    const int rc = sdmi_groupnorm_static_init();
+    if (rc) return rc;
+  }
+  unsigned char* ptr = g_gn_static_ptr[dev];
   return sdmi_groupnorm(x, ldx, y, ldy, n, hw, c, groups, gamma, beta, eps, flags, (float*)ptr, ptr + ss_bytes, stream);
 }
 
@@ -704,53 +724,3 @@ extern "C" int sdmi_layernorm(const void* x, int ldx, const float* gamma, const 
   return sdmi_check_launch("layernorm");
 }
 
-// ------------------------------------------------------------------------------------ row softmax
-// block per row: y = softmax(x*scale) , fp32 in (L2-resident re-reads), bf16 out.
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, u16* __restrict__ y, int ldy,
-                                                           int cols, float scale_log2) {
-  __shared__ float red[4];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const float* xr = x + (long long)blockIdx.x * ldx;
-  u16* yr = y + (long long)blockIdx.x * ldy;
-  const int c4 = cols >> 2;
-  float mx = -1e30f;
-  for (int i = t; i < c4; i += 256) {
-    const float4 v = ((const float4*)xr)[i];
-    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-  }
-  for (int i = c4 * 4 + t; i < cols; i += 256) mx = fmaxf(mx, xr[i]);
-  mx = wave_max(mx);
-  if (lane == 0) red[wv] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2;
-  __syncthreads();
-  float sum = 0.f;
-  for (int i = t; i < c4; i += 256) {
-    const float4 v = ((const float4*)xr)[i];
-    sum += __builtin_amdgcn_exp2f(v.x * scale_log2 - mx) + __builtin_amdgcn_exp2f(v.y * scale_log2 - mx) +
-           __builtin_amdgcn_exp2f(v.z * scale_log2 - mx) + __builtin_amdgcn_exp2f(v.w * scale_log2 - mx);
-  }
-  for (int i = c4 * 4 + t; i < cols; i += 256) sum += __builtin_amdgcn_exp2f(xr[i] * scale_log2 - mx);
-  sum = wave_sum(sum);
-  if (lane == 0) red[wv] = sum;
-  __syncthreads();
-  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
-  for (int i = t; i < c4; i += 256) {
-    const float4 v = ((const float4*)xr)[i];
-    const uint2 o = make_uint2(pack2h(__builtin_amdgcn_exp2f(v.x * scale_log2 - mx) * inv, __builtin_amdgcn_exp2f(v.y * scale_log2 - mx) * inv),
-                               pack2h(__builtin_amdgcn_exp2f(v.z * scale_log2 - mx) * inv, __builtin_amdgcn_exp2f(v.w * scale_log2 - mx) * inv));
-    ((uint2*)yr)[i] = o;
-  }
-  for (int i = c4 * 4 + t; i < cols; i += 256) yr[i] = f2h(__builtin_amdgcn_exp2f(xr[i] * scale_log2 - mx) * inv);
-}
-
-extern "C" int sdmi_softmax_rows(const float* x, int ldx, void* y, int ldy, int rows, int cols, float scale, void* stream) {
-  SDMI_REQUIRE(x && y && rows > 0 && cols > 0, "softmax_rows: bad argument");
-  SDMI_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= cols && ldy >= cols, "softmax_rows: ldx/ldy must be multiples of 4");
-  SDMI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, "softmax_rows: alignment");
-  // scale > 0 is assumed (max(x)*scale == max(x*scale))
-  SDMI_REQUIRE(scale > 0.f, "softmax_rows: scale must be positive");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, (u16*)y, ldy, cols,
-                     scale * 1.44269504088896340736f);
-  return sdmi_check_launch("softmax_rows");
-}

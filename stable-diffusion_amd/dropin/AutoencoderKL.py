@@ -1,7 +1,6 @@
 """Drop-in for the reference's AutoencoderKL.py: same classes, constructor signatures and state_dict keys
 (`encoder.*`, `decoder.*`, `quant_conv.*`, `post_quant_conv.*`); decode()/encode() take and return NCHW fp32 tensors,
 the arithmetic runs on libsdmi355.so."""
-import numpy as np
 import torch
 from torch import nn
 
@@ -13,7 +12,8 @@ CH, CH_MULT, NUM_RES, Z_CH = 128, (1, 2, 4, 4), 2, 4
 
 
 class DiagonalGaussianDistribution(object):
-    """Posterior over latents (reference AutoencoderKL.py:8-46); elementwise host-side torch math, not a hot path."""
+    """Posterior over latents (reference AutoencoderKL.py:8-31, :45-46: what `encode()` returns and `inpaint()` samples); the
+    training-only `kl` / `nll` (:33-43) are out of scope and not carried."""
 
     def __init__(self, parameters, deterministic=False):
         self.parameters = parameters
@@ -29,19 +29,6 @@ class DiagonalGaussianDistribution(object):
         if noise is None:
             noise = torch.randn(self.mean.shape).to(device=self.parameters.device)
         return self.mean + self.std * noise
-
-    def kl(self, other=None):
-        if self.deterministic:
-            return torch.Tensor([0.])
-        if other is None:
-            return 0.5 * torch.sum(self.mean ** 2 + self.var - 1.0 - self.logvar, dim=[1, 2, 3])
-        return 0.5 * torch.sum((self.mean - other.mean) ** 2 / other.var + self.var / other.var - 1.0
-                               - self.logvar + other.logvar, dim=[1, 2, 3])
-
-    def nll(self, sample, dims=[1, 2, 3]):
-        if self.deterministic:
-            return torch.Tensor([0.])
-        return 0.5 * torch.sum(np.log(2.0 * np.pi) + self.logvar + (sample - self.mean) ** 2 / self.var, dim=dims)
 
     def mode(self):
         return self.mean

@@ -161,9 +161,8 @@ class MemoryEfficientAttnBlock(nn.Module):
             q, k, v = qkv.cols(0, c), qkv.cols(c, c), qkv.cols(2 * c, c)
             o = E.attention_d512(q, k, v, log2q=True) if c == 512 else E.attention(q, k, v, 1, log2q=True)
             return E.gemm(o, E.packed_linear((self.proj_out.weight,)), c, bias=self.proj_out.bias, residual=a, out=out)
-        qk = E.gemm(xn, E.packed_linear((self.q.weight, self.k.weight)), 2 * c, bias=E.stacked_f32((self.q.bias, self.k.bias)))
-        o = E.vae_attention_core(qk, xn, E.packed_linear((self.v.weight,)), self.v.bias, c)
-        return E.gemm(o, E.packed_linear((self.proj_out.weight,)), c, bias=self.proj_out.bias, residual=a, out=out)
+        raise E.L.SdmiError("MemoryEfficientAttnBlock: one head of %d channels has no kernel (512, the reference's only "
+                            "configuration, and 64 are built)" % c)
 
     def forward(self, x):
         return E.to_nchw(self.run(E.from_nchw(x)))

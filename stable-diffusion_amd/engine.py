@@ -182,6 +182,7 @@ def stacked_f32(params, scales=None):
 # --------------------------------------------------------------------------- split-K workspace
 _WS = {}
 _WS_RETIRED = []
+_WS_WARNED = []
 
 
 def _workspace(device, nbytes):
@@ -196,10 +197,16 @@ def _workspace(device, nbytes):
             _WS_RETIRED.append(t)       # a captured HIP graph may still address it: never freed (sizes double, so the
             nbytes = max(nbytes, 2 * t.numel() * 4)   # retired buffers add up to less than the live one)
         t = torch.empty(((max(nbytes, 64 << 20) + 3) // 4,), dtype=torch.float32, device=device)
-        # a bank of arrival counters for the in-launch split-K reduction; when all 16 banks of the device are taken
-        # (many samplers alive at once) this workspace simply keeps the separate reduce kernel
-        import ctypes as C
-        L.load().sdmi_ws_tickets_init(C.c_void_p(t.data_ptr()), C.c_void_p(_stream()))
+        if WS_FLAGS:
+            # opt-in in-launch split-K reduction: a bank of arrival counters per workspace (16 per device).  A retired
+            # workspace keeps its bank (a captured graph may still run launches that count in it); when no bank is free this
+            # workspace keeps the separate reduce kernel, said once
+            import ctypes as C
+            if L.load().sdmi_ws_tickets_init(C.c_void_p(t.data_ptr()), C.c_void_p(_stream())) != 0 and not _WS_WARNED:
+                _WS_WARNED.append(True)
+                import warnings
+                warnings.warn("SDMI_SPLITK_INKERNEL=1: %s; this workspace runs the split-K reduce kernel" %
+                              L.load().sdmi_last_error().decode())
         _WS[key] = t
     return t.data_ptr(), t.numel() * 4
 
@@ -498,37 +505,6 @@ def attention_d512(q, k, v, out=None, log2q=False):
         L.call("sdmi_attention_d512_log2q", *(args + (_stream(),)))
     else:
         L.call("sdmi_attention_d512", *(args + (512.0 ** -0.5, _stream())))
-    return o
-
-
-def vae_attention_core(qk, xn, wv_packed, bv, c):
-    """Single-head attention over hw tokens with d = c (VAE mid block, layers/SpatialTransformer.py:140-158) as
-    score GEMM -> row softmax -> value GEMM, chunked over images.  qk: Act with q in cols [0,c), k in [c,2c);
-    xn: the normalised input (V is produced transposed, [c][hw], so the value GEMM reads it K-contiguous; V's bias is
-    added after the product since softmax rows sum to 1)."""
-    n, hw, dev = qk.n, qk.hw, qk.device
-    hwp = (hw + 7) // 8 * 8
-    o = new_act(n, qk.h, qk.w, c, dev)
-    per = max(1, min(n, int((1 << 31) // (hw * hwp * 4))))
-    st = _stream()
-    alloc = torch.zeros if hwp != hw else torch.empty
-    s = torch.empty((per, hw, hwp), dtype=torch.float32, device=dev)
-    p = alloc((per, hw, hwp), dtype=act_dtype(), device=dev)
-    vt = alloc((per, c, hwp), dtype=act_dtype(), device=dev)
-    scale = float(c) ** -0.5
-    for i0 in range(0, n, per):
-        nb = min(per, n - i0)
-        img = lambda act: act.ptr + 2 * i0 * act.hw * act.ld
-        # V^T[c][hw] = Wv[c][:] . xn[hw][:]
-        L.call("sdmi_gemm", wv_packed.data_ptr(), c, 0, img(xn), xn.ld, hw * xn.ld, vt.data_ptr(), hwp, c * hwp,
-               c, hw, c, nb, 0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, st)
-        # S = q k^T (fp32, unscaled; the softmax applies 1/sqrt(c))
-        L.call("sdmi_gemm", img(qk), qk.ld, hw * qk.ld, img(qk) + 2 * c, qk.ld, hw * qk.ld, s.data_ptr(), hwp, hw * hwp,
-               hw, hw, c, nb, 0, 0, 0, 0, 0, 0, 1.0, L.F_OUT_F32, 0, 0, st)
-        L.call("sdmi_softmax_rows", s.data_ptr(), hwp, p.data_ptr(), hwp, nb * hw, hw, scale, st)
-        # O = P V + bv
-        L.call("sdmi_gemm", p.data_ptr(), hwp, hw * hwp, vt.data_ptr(), hwp, c * hwp, img(o), o.ld, hw * o.ld,
-               hw, c, hwp, nb, _ptr(bv), 0, 0, 0, 0, 0, 1.0, L.F_BIAS if bv is not None else 0, 0, 0, st)
     return o
 
 

@@ -174,16 +174,6 @@ def test_attention_rescale_branch_and_batch():
     assert torch.isfinite(out.buf.float()).all()
 
 
-def test_softmax_rows():
-    rs = _rs(9)
-    x = _t(rs.randn(33, 200) * 4)
-    ref = torch.softmax(x * 0.3, dim=-1)
-    y = torch.empty((33, 200), dtype=H16, device=DEV)
-    xd = x.to(DEV)
-    L.call("sdmi_softmax_rows", xd.data_ptr(), 200, y.data_ptr(), 200, 33, 200, 0.3, E._stream())
-    _check(y, ref, 1.5e-3, 6e-4, "softmax_rows")
-
-
 def test_small_linear_and_timestep_embedding(golden):
     rs = _rs(4)
     x, w, b = _t(rs.randn(4, 1280)), _t(rs.randn(650, 1280) / 36), _t(rs.randn(650))

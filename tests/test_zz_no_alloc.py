@@ -60,3 +60,24 @@ def test_groupnorm_static_rejects_oversize():
     with pytest.raises(L.SdmiError, match="static buffer holds"):
         L.call("sdmi_groupnorm_static", a.ptr, 2560, y.data_ptr(), 2560, 64, 512 * 512, 2560, 32, gamma.data_ptr(),
                beta.data_ptr(), 1e-5, 0, st)
+
+
+def test_groupnorm_static_under_graph_capture():
+    """For the callers it exists for: after sdmi_groupnorm_static_init() the call is capturable (the symbol lookup is not
+    a stream operation and has already happened), and a replay of the captured graph writes the bits of the eager call."""
+    lib = L.load()
+    assert lib.sdmi_groupnorm_static_init() == 0
+    a, gamma, beta, silu = _case(2, 48, 48, 320, 5, True)
+    ref = E.groupnorm(a, gamma, beta, 1e-5, silu).buf
+    y = torch.full_like(a.buf, 3.0)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            L.call("sdmi_groupnorm_static", a.ptr, a.ld, y.data_ptr(), y.shape[-1], a.n, a.hw, a.c, 32, gamma.data_ptr(),
+                   beta.data_ptr(), 1e-5, L.F_SILU, torch.cuda.current_stream().cuda_stream)
+    y.fill_(3.0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ref.view(torch.int16), y.view(torch.int16))
