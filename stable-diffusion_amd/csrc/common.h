@@ -49,7 +49,9 @@ void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the 
   X(attn_d512_variant, 0, "d = 512 attention: 0 automatic (8-wave kernel), 1 the 4-wave kernel, 2 the 8-wave kernel")                            \
   X(gemm_small_m_tile, 1, "1: 64x64 tiles for K >= 2048 GEMMs with fewer than 1024 rows (0: 64x128 as in round 1)")                              \
   X(attn_x2_min_nq, 0, "> 0: query rows from which long self-attention takes the 64-rows-per-wave kernel (default 2048)")                        \
-  X(attn_variant, 0, "attention kernel variant (0 = default)")
+  X(attn_variant, 0, "attention kernel variant (0 = default)")                                                                                   \
+  X(gemm_buf_off, 0, "1: GEMMs stage with the round-2 pointer-per-lane loader instead of buffer descriptors, A/B switch")                         \
+  X(conv_win_v1, 0, "1: shared-window convs on the round-2 kernel (global_load_lds + per-lane pointers), A/B switch")
 enum SdmiOpt {
 #define SDMI_OPT_ENUM(name, def, doc) OPT_##name,
   SDMI_OPTIONS(SDMI_OPT_ENUM)

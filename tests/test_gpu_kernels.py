@@ -244,7 +244,7 @@ def test_conv_shared_window_kernel(n, cin, cout, h, w, tile, splits):
     finally:
         lib.sdmi_tune_override(-1, -1)
         lib.sdmi_tune_conv_window(-1)
-    assert outs[1][1].startswith("conv_win_kernel") and outs[0][1].startswith("igemm_kernel"), (outs[1][1], outs[0][1])
+    assert outs[1][1].startswith("conv_win") and outs[0][1].startswith("igemm_kernel"), (outs[1][1], outs[0][1])
     if h * w < 128:
         ref = ref - temb[:, :, None, None]
     _check(outs[1][0], ref, 1.5e-3, 6e-4, "shared-window conv")

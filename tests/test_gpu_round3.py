@@ -123,3 +123,104 @@ def test_layernorm_fold_rows_with_large_mean(m, c, nout):
     # the fold sees the 16-bit weights times gamma and (sum, sumsq) in fp32: a few 1e-3 at this mean/std ratio is the
     # representation's limit (fp16 quantum at 50 is 0.03 = 6 % of the spread, identical for both paths' INPUT)
     assert e_fold < 4e-3 * _tol() and e_plain < 2e-3 * _tol(), (e_fold, e_plain)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round-3 shared-window conv kernel (buffer-descriptor staging, shift-proof LDS swizzle) against the round-2 kernel it
+# replaces and the generic im2col kernel: the same bits (K order, arithmetic and epilogue are shared)
+@pytest.mark.parametrize("n,hh,ww,cin,cout,stats,tile,splits", [
+    (1, 96, 96, 320, 320, True, -1, -1),      # the UNet's most frequent conv; statistics from the epilogue
+    (2, 48, 48, 640, 640, False, -1, -1),     # CFG batch 2 of the 48x48 level
+    (1, 48, 48, 1280, 640, True, -1, -1),     # split-K (90 tiles): partials + reduce kernel, statistics from the reduce kernel
+    (3, 20, 12, 128, 192, False, 2, 1),       # 240-pixel images: tiles span two images, rows wrap inside tiles, N % 64 = 0
+    (3, 20, 12, 128, 192, False, 1, 2),       # the same on 128 x 128 tiles (N % 128 = 64), split-K 2
+    (1, 24, 24, 2560, 1280, False, -1, -1),   # long K, split-K
+    (1, 100, 60, 64, 128, False, 1, 1),       # one channel chunk; M % 128 = 112
+])
+def test_conv_win2_bit_identical_to_conv_win_and_generic(n, hh, ww, cin, cout, stats, tile, splits):
+    lib = L.load()
+    rs = np.random.RandomState(n * hh + cin)
+    H = E.act_dtype()
+    x = E.Act(T(rs.randn(n, hh * ww, cin).astype(np.float32)).to(DEV).to(H), n, hh, ww, cin)
+    W = torch.nn.Parameter(T((rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)).to(DEV))
+    b = T(rs.randn(cout).astype(np.float32)).to(DEV)
+    res = E.Act(T(rs.randn(n, hh * ww, cout).astype(np.float32)).to(DEV).to(H), n, hh, ww, cout)
+    temb = T(rs.randn(n, cout).astype(np.float32)).to(DEV)
+    saved = E.USE_COLSTATS
+    outs, kern, cstat = {}, {}, {}
+    try:
+        E.USE_COLSTATS = stats
+        lib.sdmi_tune_override(tile, splits)
+        for mode in ("v2", "v1", "generic"):
+            lib.sdmi_set_option(b"conv_win_v1", 1 if mode == "v1" else 0)
+            lib.sdmi_tune_conv_window(0 if mode == "generic" else -1)
+            y = E.conv3x3(x, W, b, rowbias=temb if hh * ww >= 128 else None, ldrb=cout, residual=res)
+            torch.cuda.synchronize()
+            outs[mode], kern[mode] = y.buf.clone(), lib.sdmi_last_kernel().decode()
+            cstat[mode] = y.stats.get(0)
+    finally:
+        E.USE_COLSTATS = saved
+        lib.sdmi_set_option(b"conv_win_v1", 0)
+        lib.sdmi_tune_conv_window(-1)
+        lib.sdmi_tune_override(-1, -1)
+    print(kern)
+    assert kern["v2"].startswith("conv_win2_kernel") and kern["v1"].startswith("conv_win_kernel") and kern["generic"].startswith("igemm_kernel")
+    assert torch.equal(outs["v2"].view(torch.int16), outs["v1"].view(torch.int16)), "round-3 and round-2 window kernels differ"
+    assert torch.equal(outs["v2"].view(torch.int16), outs["generic"].view(torch.int16)), "window and generic kernels differ"
+    if stats:
+        assert cstat["v2"] is not None and cstat["v1"] is not None
+        assert torch.equal(cstat["v2"][0], cstat["v1"][0]), "column statistics differ"
+    ref = torch.nn.functional.conv2d(x.buf.float().reshape(n, hh, ww, cin).permute(0, 3, 1, 2), W.detach().to(H).float(), b, padding=1)
+    ref = ref + res.buf.float().reshape(n, hh, ww, cout).permute(0, 3, 1, 2) + (temb[:, :, None, None] if hh * ww >= 128 else 0.0)
+    e = rel_err(outs["v2"].float().reshape(n, hh, ww, cout).permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy())
+    assert e[1] < 6e-4 * _tol(), e
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GEMM staging through buffer descriptors (round 3) against the pointer-per-lane loader: same bits on every epilogue
+@pytest.mark.parametrize("m,n,k,kind", [
+    (9216, 320, 320, "res"),         # 128 x 64 tiles, residual + bias + row statistics
+    (9216, 960, 320, "ln"),          # LayerNorm folded in
+    (9216, 2560, 320, "geglu"),      # GEGLU, 128 x 128 tiles
+    (2304, 640, 2560, "res"),        # 64 x 64 tiles, long K
+    (1000, 328, 192, "plain"),       # rows and columns that end inside a tile (M % 64 = 40, N % 64 = 8)
+    (288, 1280, 5120, "plain"),      # split-K
+    (576, 10240, 1280, "geglu"),     # 64 x 128 GEGLU tiles
+])
+def test_gemm_buffer_staging_bit_identical(m, n, k, kind):
+    lib = L.load()
+    rs = np.random.RandomState(m + n + k)
+    H = E.act_dtype()
+    a = E.Act(T(rs.randn(1, m, k).astype(np.float32)).to(DEV).to(H), 1, 1, m, k)
+    w = T((rs.randn(n, k) / np.sqrt(k)).astype(np.float32)).to(DEV).to(H).contiguous()
+    b = T(rs.randn(n).astype(np.float32)).to(DEV)
+    nout = n // 2 if kind == "geglu" else n
+    res = E.Act(T(rs.randn(1, m, nout).astype(np.float32)).to(DEV).to(H), 1, 1, m, nout) if kind == "res" else None
+    ln = None
+    if kind == "ln":
+        w0 = T((rs.randn(k, k) / np.sqrt(k)).astype(np.float32)).to(DEV).to(H).contiguous()
+        a = E.gemm(a, w0, k, rowstats=True)
+        lnm = torch.nn.LayerNorm(k).to(DEV)
+        W1 = torch.nn.Parameter(w.float())
+    outs, kern = {}, {}
+    try:
+        for off in (0, 1):
+            lib.sdmi_set_option(b"gemm_buf_off", off)
+            if kind == "ln":
+                y = E.gemm_ln(a, lnm, (W1,), bias=torch.nn.Parameter(b))
+            else:
+                y = E.gemm(a, w, n, bias=b, residual=res, geglu=(kind == "geglu"), rowstats=(kind == "res"))
+            torch.cuda.synchronize()
+            outs[off], kern[off] = y.buf.clone(), lib.sdmi_last_kernel().decode()
+            if kind == "res":
+                outs[("rs", off)] = y.rstats[0].clone() if y.rstats is not None else None
+    finally:
+        lib.sdmi_set_option(b"gemm_buf_off", 0)
+    print(kern)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "buffer-descriptor and pointer loaders differ"
+    if kind == "res" and outs[("rs", 0)] is not None:
+        assert torch.equal(outs[("rs", 0)], outs[("rs", 1)])
+    if kind in ("plain", "res"):
+        ref = a.buf[0].float() @ w.float().t() + b + (res.buf[0].float() if res is not None else 0.0)
+        e = rel_err(outs[0][0].float().cpu().numpy(), ref.cpu().numpy())
+        assert e[1] < 6e-4 * _tol(), e
