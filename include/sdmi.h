@@ -283,6 +283,13 @@ int sdmi_cfg_ddim_step(const float* eps, const float* x, const float* noise, flo
                        float a_prev, float sigma, float temperature, float* x_out, float* pred_x0, float* xc_out,
                        int xc_channels, int b, int chw, void* stream);
 
+/* ---- range audit, no counterpart in the reference (fp32 there never clips).  The fp16 build SATURATES on store: a value
+ *      beyond +-65504 is stored as +-65504, silently.  sdmi_count_saturated adds to *count_u64 (device uint64, zeroed by the
+ *      caller) the elements of an h16 [rows][ld] view (first `cols` columns) with |x| >= 65504 or non-finite, so that a
+ *      caller can audit a checkpoint layer by layer (stable-diffusion_amd/engine.py RANGE_AUDIT does) and switch to the bf16
+ *      build (-DSDMI_BF16) when any layer clips. */
+int sdmi_count_saturated(const void* x, int ld, int rows, int cols, void* count_u64, void* stream);
+
 /* ---- measurement probes, no counterpart in the reference (roofline fractions are reported against the
  *      nominal and the MEASURED peak of the box).  sdmi_probe_mfma launches `blocks` blocks of 4 waves that each issue
  *      8 * iters v_mfma_f32_32x32x16 (2*32*32*16 flop each) and nothing else; sdmi_probe_copy streams `bytes` from src

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "sdmi_groupnorm_static": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _u32, _vp]),
     "sdmi_groupnorm_static_max_bytes": (_i64, []),
     "sdmi_groupnorm_static_init": (_i, []),
+    "sdmi_count_saturated": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "sdmi_layernorm": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "sdmi_conv3x3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp, _i64, _vp]),
     "sdmi_conv3x3_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),

@@ -51,6 +51,7 @@ void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the 
   X(attn_x2_min_nq, 0, "> 0: query rows from which long self-attention takes the 64-rows-per-wave kernel (default 2048)")                        \
   X(attn_variant, 0, "attention kernel variant (0 = default)")                                                                                   \
   X(gemm_buf_off, 0, "1: GEMMs stage with the round-2 pointer-per-lane loader instead of buffer descriptors, A/B switch")                         \
+  X(conv_win_var, 0, "experiment variant of conv_win2_kernel (template VAR)")                                                                     \
   X(conv_win_v1, 0, "1: shared-window convs on the round-2 kernel (global_load_lds + per-lane pointers), A/B switch")
 enum SdmiOpt {
 #define SDMI_OPT_ENUM(name, def, doc) OPT_##name,

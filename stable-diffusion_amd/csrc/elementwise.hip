@@ -391,3 +391,34 @@ extern "C" int sdmi_gelu_rows(void* x, int ldx, int rows, int cols, void* stream
   hipLaunchKernelGGL(gelu_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (u16*)x, ldx, rows, cols);
   return sdmi_check_launch("gelu_rows");
 }
+
+// ------------------------------------------------------------------------------------ range audit (debug aid)
+// The fp16 build saturates on store (f2h16): an activation beyond +-65504 is clipped, silently.  This counts the elements of
+// an h16 [rows][ld] view (cols used) that sit AT the clip value (|x| >= 65504, or non-finite) into *count (uint64, the caller
+// zeroes it): the drop-in's range audit (engine.RANGE_AUDIT) calls it behind every conv / GEMM to say which layer of a
+// given checkpoint would need the bf16 build.  Integer atomics: the count does not depend on the order of arrival.
+__global__ __launch_bounds__(256) void count_saturated_kernel(const u16* __restrict__ x, int ld, int rows, int cols,
+                                                              unsigned long long* __restrict__ count) {
+  unsigned local = 0;
+  const long long total = (long long)rows * cols;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    const float v = fabsf(h2f(x[(long long)r * ld + c]));
+    local += !(v < 65504.0f);   // true for the clip value, inf and NaN
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, (unsigned long long)local);
+}
+
+extern "C" int sdmi_count_saturated(const void* x, int ld, int rows, int cols, void* count_u64, void* stream) {
+  SDMI_REQUIRE(x && count_u64 && rows > 0 && cols > 0 && ld >= cols, "count_saturated: bad argument");
+  SDMI_REQUIRE(((uintptr_t)count_u64 & 7) == 0, "count_saturated: the counter must be 8-byte aligned");
+  const long long total = (long long)rows * cols;
+  long long blocks = (total + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(count_saturated_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)x, ld, rows, cols,
+                     (unsigned long long*)count_u64);
+  return sdmi_check_launch("count_saturated");
+}

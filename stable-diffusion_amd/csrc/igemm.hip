@@ -1245,8 +1245,10 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(const IgemmParams p) {
 // Same K order, same arithmetic, same epilogue as conv_win_kernel and igemm_kernel: same bits (tested).
 // Needs Cin % 64 == 0 and panels below 2 GB (host); everything else keeps conv_win_kernel.
 __device__ __forceinline__ int lds_off_w(int row, int chunk) { return row * BK + ((chunk ^ (((row >> 1) & 3) << 1)) << 3); }
-template <int BM, int BN, bool CS>
-__global__ __launch_bounds__(256, 2) void conv_win2_kernel(const IgemmParams p) {
+// VAR (experiments, conv_win_var option): bit 0 = scheduling fences that keep a step's fragment reads in front of the previous
+// step's MFMAs (the compiler otherwise sinks them to their first use), bit 1 = s_setprio around the MFMA batches
+template <int BM, int BN, bool CS, int VAR = 0>
+__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_win2_kernel(const IgemmParams p) {
   constexpr int TM = BM / 2, TN = BN / 2, MT = TM / 16, NT = TN / 16;
   constexpr int WROWS = BM + 8;           // staged window rows: BM + 2 are read; whole 8-row DMA instructions
   constexpr int WBUF = (WROWS + 1) * BK;  // elements per window buffer, + one row of zeros
@@ -1344,11 +1346,15 @@ __global__ __launch_bounds__(256, 2) void conv_win2_kernel(const IgemmParams p) 
     const u16* cB = bring + (SLOT) * BSLOT;                                                                         \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) AF[i] = *(const hx8*)&(WB)[aoff[i][KX] ^ ((KK) ? 32 : 0)];       \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const hx8*)&cB[boff[j] ^ ((KK) ? 32 : 0)];             \
+    if constexpr (VAR & 1) __builtin_amdgcn_sched_barrier(0);                                                       \
   }
 #define WIN2_MFMA(AF, WF)                                                                                  \
   {                                                                                                        \
+    if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);                                                  \
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                         \
       _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(WF[j], AF[i], acc[i][j], 0, 0, 0); \
+    if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);                                                  \
+    if constexpr (VAR & 1) __builtin_amdgcn_sched_barrier(0);                                              \
   }
 
   f32x4 acc[MT][NT];
@@ -1643,6 +1649,34 @@ static void stats_parts_of(const IgemmParams& p, int batch, int vi, int* row_par
   if (col_parts) *col_parts = (plain && p.N % 32 == 0) ? p.N / 32 : 0;
 }
 
+// conv_win2_kernel launch: instantiation by (statistics, experiment variant); > 64 KB of dynamic LDS allowed once per device
+template <int BM, int BN, bool CS, int VAR>
+static void launch_win2_v(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
+  auto kfn = conv_win2_kernel<BM, BN, CS, VAR>;
+  static unsigned long long attr_done = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (bytes > 65536 && !((attr_done >> (dev & 63)) & 1ull)) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    attr_done |= 1ull << (dev & 63);
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), bytes, st, p);
+}
+template <int BM, int BN>
+static void launch_win2(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
+  const int var = sdmi_opt(OPT_conv_win_var);
+#define WIN2_CASE(V)                                                        \
+  case V:                                                                   \
+    if (p.colstats) launch_win2_v<BM, BN, true, V>(grid, bytes, st, p);     \
+    else launch_win2_v<BM, BN, false, V>(grid, bytes, st, p);               \
+    break;
+  switch (var) {
+    WIN2_CASE(1) WIN2_CASE(2) WIN2_CASE(3)
+    default: WIN2_CASE(0)
+  }
+#undef WIN2_CASE
+}
+
 template <bool CONV>
 static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st, const sdmi_epilogue_ext* ext = nullptr) {
   p.ws = nullptr;
@@ -1717,20 +1751,16 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         if (!((attr_done >> (dev & 63)) & 1ull)) {
           (void)hipFuncSetAttribute((const void*)conv_win_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
           (void)hipFuncSetAttribute((const void*)conv_win_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
-          (void)hipFuncSetAttribute((const void*)conv_win2_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
-          (void)hipFuncSetAttribute((const void*)conv_win2_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
           attr_done |= 1ull << (dev & 63);
         }
         if (v2) {
-          if (p.colstats) hipLaunchKernelGGL((conv_win2_kernel<128, 128, true>), grid, dim3(256), wbytes128, st, p);
-          else hipLaunchKernelGGL((conv_win2_kernel<128, 128, false>), grid, dim3(256), wbytes128, st, p);
+          launch_win2<128, 128>(grid, wbytes128, st, p);
         } else {
           if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 128, true>), grid, dim3(256), wbytes128, st, p);
           else hipLaunchKernelGGL((conv_win_kernel<128, 128, false>), grid, dim3(256), wbytes128, st, p);
         }
       } else if (v2) {
-        if (p.colstats) hipLaunchKernelGGL((conv_win2_kernel<128, 64, true>), grid, dim3(256), wbytes64, st, p);
-        else hipLaunchKernelGGL((conv_win2_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);
+        launch_win2<128, 64>(grid, wbytes64, st, p);
       } else {
         if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 64, true>), grid, dim3(256), wbytes64, st, p);
         else hipLaunchKernelGGL((conv_win_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);

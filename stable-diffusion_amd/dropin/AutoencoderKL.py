@@ -48,6 +48,7 @@ def _conv_in(x, conv):
     a = E.new_act(n, h, w, conv.out_channels, x.device)
     E.L.call("sdmi_conv3x3_in", x.data_ptr(), n, c, h, w, conv.weight.data_ptr(), conv.bias.data_ptr(), conv.out_channels,
              a.ptr, a.ld, E._stream())
+    E._audit("conv_in %d->%d @%dx%d" % (c, conv.out_channels, h, w), a)
     return a
 
 

@@ -225,6 +225,26 @@ def _check_out(res, n, h, w, c, what):
                           (what, res.n, res.h, res.w, res.c, n, h, w, c))
 
 
+# --------------------------------------------------------------------------- range audit (debug aid)
+# The fp16 build saturates on store: a checkpoint whose activations pass +-65504 somewhere (VAE up-blocks are the usual
+# place) is clipped there, silently.  With RANGE_AUDIT = True every conv / GEMM result is scanned by sdmi_count_saturated and
+# RANGE_LOG collects (op, rows, channels, clipped elements) for the layers that clip: run one image that way when a new
+# checkpoint is loaded; any entry means "use the bf16 build" (-DSDMI_BF16).  Off in production (one extra launch per op;
+# not capturable: it reads the counter back).
+RANGE_AUDIT = False
+RANGE_LOG = []
+
+
+def _audit(what, res):
+    if not RANGE_AUDIT or not isinstance(res, Act) or act_dtype() != torch.float16:
+        return
+    cnt = torch.zeros((1,), dtype=torch.int64, device=res.device)
+    L.call("sdmi_count_saturated", res.ptr, res.ld, res.n * res.hw, res.c, cnt.data_ptr(), _stream())
+    n = int(cnt.item())
+    if n:
+        RANGE_LOG.append((what, res.n * res.hw, res.c, n))
+
+
 # --------------------------------------------------------------------------- ops
 USE_COLSTATS = os.environ.get("SDMI_COLSTATS", "1") == "1"     # GroupNorm statistics from the producer's epilogue (A/B switch)
 USE_LNFOLD = os.environ.get("SDMI_LNFOLD", "1") == "1"         # LayerNorm folded into the GEMM that follows it (A/B switch)
@@ -344,6 +364,7 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
     L.call("sdmi_conv3x3_ex", a.ptr, a.ld, a.n, a.h, a.w, cin, wp.data_ptr(), cout, ho, wo, stride, pt, pl,
            _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags | (WS_FLAGS if ws else 0), ws, wsb, _stream(),
            ctypes.addressof(ext) if ext is not None else 0)
+    _audit("conv3x3 %d->%d @%dx%d" % (cin, cout, ho, wo), res)
     return res
 
 
@@ -394,6 +415,7 @@ def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shap
     L.call("sdmi_gemm_ex", a.ptr, a.ld, 0, wp.data_ptr(), wp.shape[1], 0, res.ptr, res.ld, 0, m, n_out, a.c, 1,
            _ptr(bias), 0, 0, a.hw, res_ptr, ldr, 1.0, flags | (WS_FLAGS if ws else 0), ws, wsb, _stream(),
            ctypes.addressof(ext) if ext is not None else 0)
+    _audit("gemm %dx%dx%d" % (m, n_out, a.c), res)
     return res
 
 

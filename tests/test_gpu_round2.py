@@ -405,10 +405,11 @@ def test_attention_kv_split_kernel_vs_fp64(attn_variant, b, heads, nq, nkv, kind
     # log2q: q is exact in the kernel, same error budget as the 32-row kernel; scale path: q is re-rounded after scaling,
     # which costs precision with wide logits (the UNet does not use that path on this kernel)
     l2 = lambda a, b_: float((a - b_).norm() / b_.norm())
-    assert l2(outs[-1], want) < 6e-4 and l2(outs[-1, "l"], want_l) < 6e-4
-    assert l2(outs[1, "l"], want_l) < 6e-4
-    assert l2(outs[1, "l"], outs[-1, "l"]) < 6e-4
-    assert l2(outs[1], want) < (6e-4 if kind != "wide" else 2.5e-3)
+    gate = 6e-4 * _tol()                         # (the bf16 build keeps 8 significant bits of P and V)
+    assert l2(outs[-1], want) < gate and l2(outs[-1, "l"], want_l) < gate
+    assert l2(outs[1, "l"], want_l) < gate
+    assert l2(outs[1, "l"], outs[-1, "l"]) < gate
+    assert l2(outs[1], want) < (gate if kind != "wide" else 2.5e-3 * _tol())
     assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[1, "l"]).all()
 
 

@@ -224,3 +224,33 @@ def test_gemm_buffer_staging_bit_identical(m, n, k, kind):
         ref = a.buf[0].float() @ w.float().t() + b + (res.buf[0].float() if res is not None else 0.0)
         e = rel_err(outs[0][0].float().cpu().numpy(), ref.cpu().numpy())
         assert e[1] < 6e-4 * _tol(), e
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp16 dynamic range (round-2 review): the library saturates on store, so a checkpoint whose VAE activations pass 65504 is
+# clipped.  The clip is not silent to a caller who asks: engine.RANGE_AUDIT counts the clipped elements per layer.
+def test_range_audit_reports_clipped_vae_layers():
+    if E.act_dtype() != torch.float16:
+        pytest.skip("bf16 build: no clip below 3e38")
+    from AutoencoderKL import AutoencoderKL
+    vae = AutoencoderKL()
+    fill_state_dict(vae.state_dict(), seed=1, fast=True)
+    vae = vae.to(DEV).eval()
+    z = T(np.random.RandomState(3).randn(1, 4, 16, 16).astype(np.float32)).to(DEV)
+    E.RANGE_LOG.clear()
+    E.RANGE_AUDIT = True
+    try:
+        with torch.no_grad():
+            ok = vae.decode(z)
+        assert E.RANGE_LOG == [], "unit-scale weights must not clip: %r" % (E.RANGE_LOG[:3],)
+        # a "checkpoint" whose decoder input conv is 3e4 times larger: the first activations pass 65504 and are clipped
+        with torch.no_grad():
+            vae.decoder.conv_in.weight.mul_(3.0e4)
+            vae.decoder.conv_in.bias.mul_(3.0e4)
+            big = vae.decode(z)
+    finally:
+        E.RANGE_AUDIT = False
+    print("range audit:", E.RANGE_LOG[:4])
+    assert len(E.RANGE_LOG) >= 1 and E.RANGE_LOG[0][0].startswith("conv") and E.RANGE_LOG[0][3] > 0
+    assert torch.isfinite(ok).all() and torch.isfinite(big).all()      # saturation, not inf / NaN (GroupNorm renormalises)
+    E.RANGE_LOG.clear()
