@@ -9,6 +9,8 @@ dev = "cuda"; H = E.act_dtype()
 torch.manual_seed(0)
 REP = int(os.environ.get("REP", "5"))
 lib = _lib.load()
+for kv in filter(None, os.environ.get("SDMI_OPTS", "").split(",")):   # e.g. SDMI_OPTS=attn_pp=-1
+    lib.sdmi_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1]))
 for spec in sys.argv[1:]:
     f = spec.split(":")
     kind = f[0]
@@ -34,7 +36,7 @@ for spec in sys.argv[1:]:
             E.conv3x3(x, W, b, residual=res, out=out)
     elif kind == "attn":
         b_, h, nq, nkv = int(f[1]), int(f[2]), int(f[3]), int(f[4])
-        q = E.Act(torch.randn(b_, nq, h * 64, device=dev).to(H), b_, 1, nq, h * 64)
+        q = E.Act((torch.randn(b_, nq, h * 64, device=dev) * E.Q_LOG2_SCALE).to(H), b_, 1, nq, h * 64)
         kk = E.Act(torch.randn(b_, nkv, h * 64, device=dev).to(H), b_, 1, nkv, h * 64)
         v = E.Act(torch.randn(b_, nkv, h * 64, device=dev).to(H), b_, 1, nkv, h * 64)
         for _ in range(REP):

@@ -289,13 +289,12 @@ __device__ __forceinline__ void attn2_block(const u16* sK, const u16* sV, int kb
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pb[qb][j] = (h16)__builtin_amdgcn_exp2f(s[qb][8 * s2 + j]);
-      // row sums of the rounded P (what the PV product sees), two elements per instruction
-      union { hx8 v; hx2 h[4]; } u;
-      u.v = pb[qb];
-      const hx2 ones = {(h16)1.0f, (h16)1.0f};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) lrun[qb] = DOT2H(u.h[j], ones, lrun[qb]);
+      for (int j = 0; j < 4; ++j) {  // (the operations of A3_E2, in its order: the pipelined block gives the same bits)
+        const float e0 = __builtin_amdgcn_exp2f(s[qb][8 * s2 + 2 * j]), e1 = __builtin_amdgcn_exp2f(s[qb][8 * s2 + 2 * j + 1]);
+        pb[qb][2 * j] = (h16)e0;
+        pb[qb][2 * j + 1] = (h16)e1;
+        lrun[qb] += e0 + e1;
+      }
     }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
@@ -314,6 +313,168 @@ __device__ __forceinline__ void attn2_block(const u16* sK, const u16* sV, int kb
   }
 }
 
+// ------------------------------------------------------------------------------------------ software-pipelined block (round 3)
+// attn2_block issues the two chains in lockstep: 8 QK^T MFMAs with nothing beside them, then a vector-dense softmax with 8
+// PV MFMAs squeezed in (SQ counters, profiles/r02_attn_pmc_attn64x2_kernel.txt: matrix and vector pipes busy together for
+// 26 % of the matrix time).  A v_mfma_f32_32x32x16 occupies the SIMD's issue for 8 of its 32 cycles
+// (MI355X_MICROARCH.md, cycle constants): ~24 cycles of independent vector work fit beside every MFMA.  Here chain 1 LAGS
+// chain 0 by half a block - its exp / P.V for block i - 1 run beside chain 0's QK^T for block i - so that every MFMA of
+// the 16 per block has about one sixteenth of the block's softmax work (two exp2, a pack, a dot2) in its shadow:
+//     MFMA   Q0.0 Q0.1 Q0.2 Q0.3 | V1a.0 V1a.1 | Q1.0 Q1.1 Q1.2 Q1.3 | V1b.0 V1b.1 | V0a.0 V0a.1 | V0b.0 V0b.1
+//     VALU   E1a0 E1a1 E1a2 E1a3 | E1b01 E1b23 | max0 E0a0 E0a1 E0a2 | E0a3  E0b0  | E0b1  E0b23 | max1   -
+// (Qc = S^T chain c, Vcx = O^T += V^T P^T of chain c for keys 0-15 (a) / 16-31 (b) of the block, E = two scores -> one
+// packed word of P + its row-sum term, chain 1's E / V rows belong to the PREVIOUS block).  Chain 1's scores (s1) and the
+// V fragments (va, vb: registers, time-shared by chain 1's old block and chain 0's new one) live across calls; nothing of
+// an old tile is read from the LDS after its barrier.  Every chain sees the operations of attn2_block in the same order:
+// the results are bit-identical (tested).  The order is pinned with sched_barrier fences: left alone the scheduler clusters
+// the MFMAs again.
+#define A3_FENCE() __builtin_amdgcn_sched_barrier(0)
+union A3P { hx8 v; hx2 h[4]; };
+// two scores -> one packed word of P, and their part of the row sum.  The sum takes the unrounded exponentials through
+// v_add_f32: v_dot2c_f32_f16 on the rounded pair (round 2) is one instruction less, but it does not run beside another
+// wave's MFMAs (scratch/mb/coexec2.hip, profiles/r03_coexec2.txt: 32 of them next to 8 MFMAs take 245 ns, against
+// 138 | 76 ns alone, as do v_dot2_f32_f16, v_pk_mul_f32, v_pk_add_f32; v_add_f32 overlaps 64 %): -1.5 ... -4 % on the
+// long self-attention shapes.
+#define A3_E2(S, K, W, L)                                          \
+  {                                                                \
+    const float e0_ = __builtin_amdgcn_exp2f(S[2 * (K)]), e1_ = __builtin_amdgcn_exp2f(S[2 * (K) + 1]); \
+    hx2 w_;                                                        \
+    w_[0] = (h16)e0_;                                              \
+    w_[1] = (h16)e1_;                                              \
+    W = w_;                                                        \
+    L += e0_ + e1_;                                                \
+  }
+// row maximum of one chain's block and, rarely, the move of its running maximum (as in attn2_block, per chain)
+template <bool FIRST>
+__device__ __forceinline__ void a3_max(f32x16& s, f32x16 (&oacc)[2], f32x16& negm, float& mrun, float& lrun) {
+  float m0 = s[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m0 = fmaxf(m0, s[i]);
+  const bool raise = FIRST || __builtin_amdgcn_ballot_w64(m0 > ATTN_DEFER_LOG2) != 0;
+  if (raise) {
+    const float mrow = fmaxf(m0, __shfl_xor(m0, 32));
+    const float delta = FIRST ? mrow : fmaxf(mrow, 0.f);
+    mrun += delta;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] -= delta;
+    if constexpr (!FIRST) {
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      lrun *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] -= delta;
+  }
+}
+__device__ __forceinline__ hx8 a3_vfrag(const u16* sV, int kb, int s2, int dt, int hh, int dblk, int tq, int tp) {
+  const int c = 4 * dt + 2 * dblk + (tp >> 1);
+  const int row0 = 32 * kb + 16 * s2 + 4 * hh + tq;
+  const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(sV + v_off(row0, c) + 4 * (tp & 1)));
+  const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(sV + v_off(row0 + 8, c) + 4 * (tp & 1)));
+  union { struct { short4_t a, b; } h; hx8 v; } u;
+  u.h.a = lo;
+  u.h.b = hi;
+  return u.v;
+}
+template <bool TAIL>
+__device__ __forceinline__ void a3_mask(f32x16& s, int key0, int nkv, int hh) {
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (key0 + (i & 3) + 8 * (i >> 2) + 4 * hh >= nkv) s[i] = -1e30f;
+  }
+}
+
+// FIRST: the wave's first block (no block of chain 1 pending; the running maxima start here)
+template <bool FIRST, bool TAIL>
+__device__ __forceinline__ void attn3_block(const u16* sK, const u16* sV, int kb, const hx8 (&qf)[2][4], f32x16 (&oacc)[2][2],
+                                            f32x16 (&negm)[2], float (&mrun)[2], float (&lrun)[2], f32x16& s1, hx8 (&va)[2],
+                                            hx8 (&vb)[2], int key0, int nkv, int r, int hh, int dblk, int tq, int tp) {
+  hx8 kf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const hx8*)&sK[k_off(32 * kb + r, 2 * ks + hh)];
+  f32x16 s0;
+  A3P p1a, p1b, p0a, p0b;
+  // ---- Q0 | E1a
+  if constexpr (!FIRST) A3_E2(s1, 0, p1a.h[0], lrun[1]);
+  A3_FENCE();
+  asm(MFMA32_MNEMONIC " %0, %1, %2, %3" : "=&v"(s0) : "v"(kf[0]), "v"(qf[0][0]), "v"(negm[0]));
+  if constexpr (!FIRST) A3_E2(s1, 1, p1a.h[1], lrun[1]);
+  A3_FENCE();
+  s0 = MFMA32(kf[1], qf[0][1], s0, 0, 0, 0);
+  if constexpr (!FIRST) A3_E2(s1, 2, p1a.h[2], lrun[1]);
+  A3_FENCE();
+  s0 = MFMA32(kf[2], qf[0][2], s0, 0, 0, 0);
+  if constexpr (!FIRST) A3_E2(s1, 3, p1a.h[3], lrun[1]);
+  A3_FENCE();
+  s0 = MFMA32(kf[3], qf[0][3], s0, 0, 0, 0);
+  A3_FENCE();
+  // ---- V1a | E1b
+  if constexpr (!FIRST) {
+    oacc[1][0] = MFMA32(va[0], p1a.v, oacc[1][0], 0, 0, 0);
+    A3_E2(s1, 4, p1b.h[0], lrun[1]);
+    A3_E2(s1, 5, p1b.h[1], lrun[1]);
+    A3_FENCE();
+    oacc[1][1] = MFMA32(va[1], p1a.v, oacc[1][1], 0, 0, 0);
+    A3_E2(s1, 6, p1b.h[2], lrun[1]);
+    A3_E2(s1, 7, p1b.h[3], lrun[1]);
+    A3_FENCE();
+  }
+  // va is free: this block's V fragments for keys 0-15
+  va[0] = a3_vfrag(sV, kb, 0, 0, hh, dblk, tq, tp);
+  va[1] = a3_vfrag(sV, kb, 0, 1, hh, dblk, tq, tp);
+  // ---- Q1 | max0, E0a   (s1 is free: every E1 of the previous block has run)
+  asm(MFMA32_MNEMONIC " %0, %1, %2, %3" : "=&v"(s1) : "v"(kf[0]), "v"(qf[1][0]), "v"(negm[1]));
+  a3_mask<TAIL>(s0, key0, nkv, hh);
+  a3_max<FIRST>(s0, oacc[0], negm[0], mrun[0], lrun[0]);
+  A3_FENCE();
+  s1 = MFMA32(kf[1], qf[1][1], s1, 0, 0, 0);
+  A3_E2(s0, 0, p0a.h[0], lrun[0]);
+  A3_FENCE();
+  s1 = MFMA32(kf[2], qf[1][2], s1, 0, 0, 0);
+  A3_E2(s0, 1, p0a.h[1], lrun[0]);
+  A3_FENCE();
+  s1 = MFMA32(kf[3], qf[1][3], s1, 0, 0, 0);
+  A3_E2(s0, 2, p0a.h[2], lrun[0]);
+  A3_FENCE();
+  // ---- V1b | E0a3, E0b0
+  if constexpr (!FIRST) oacc[1][0] = MFMA32(vb[0], p1b.v, oacc[1][0], 0, 0, 0);
+  A3_E2(s0, 3, p0a.h[3], lrun[0]);
+  A3_FENCE();
+  if constexpr (!FIRST) oacc[1][1] = MFMA32(vb[1], p1b.v, oacc[1][1], 0, 0, 0);
+  A3_E2(s0, 4, p0b.h[0], lrun[0]);
+  A3_FENCE();
+  // vb is free: this block's V fragments for keys 16-31
+  vb[0] = a3_vfrag(sV, kb, 1, 0, hh, dblk, tq, tp);
+  vb[1] = a3_vfrag(sV, kb, 1, 1, hh, dblk, tq, tp);
+  // ---- V0a | E0b
+  oacc[0][0] = MFMA32(va[0], p0a.v, oacc[0][0], 0, 0, 0);
+  A3_E2(s0, 5, p0b.h[1], lrun[0]);
+  A3_FENCE();
+  oacc[0][1] = MFMA32(va[1], p0a.v, oacc[0][1], 0, 0, 0);
+  A3_E2(s0, 6, p0b.h[2], lrun[0]);
+  A3_E2(s0, 7, p0b.h[3], lrun[0]);
+  A3_FENCE();
+  // ---- V0b | max1
+  oacc[0][0] = MFMA32(vb[0], p0b.v, oacc[0][0], 0, 0, 0);
+  a3_mask<TAIL>(s1, key0, nkv, hh);
+  a3_max<FIRST>(s1, oacc[1], negm[1], mrun[1], lrun[1]);
+  A3_FENCE();
+  oacc[0][1] = MFMA32(vb[1], p0b.v, oacc[0][1], 0, 0, 0);
+  A3_FENCE();
+}
+// after the wave's last block: chain 1's pending exp / P.V
+__device__ __forceinline__ void attn3_drain(f32x16 (&oacc)[2][2], float (&lrun)[2], const f32x16& s1, const hx8 (&va)[2], const hx8 (&vb)[2]) {
+  A3P p1a, p1b;
+  A3_E2(s1, 0, p1a.h[0], lrun[1]); A3_E2(s1, 1, p1a.h[1], lrun[1]); A3_E2(s1, 2, p1a.h[2], lrun[1]); A3_E2(s1, 3, p1a.h[3], lrun[1]);
+  oacc[1][0] = MFMA32(va[0], p1a.v, oacc[1][0], 0, 0, 0);
+  oacc[1][1] = MFMA32(va[1], p1a.v, oacc[1][1], 0, 0, 0);
+  A3_E2(s1, 4, p1b.h[0], lrun[1]); A3_E2(s1, 5, p1b.h[1], lrun[1]); A3_E2(s1, 6, p1b.h[2], lrun[1]); A3_E2(s1, 7, p1b.h[3], lrun[1]);
+  oacc[1][0] = MFMA32(vb[0], p1b.v, oacc[1][0], 0, 0, 0);
+  oacc[1][1] = MFMA32(vb[1], p1b.v, oacc[1][1], 0, 0, 0);
+}
+
 // K/V staging of this kernel is LDS-DMA issued from inline asm (M0 = LDS base of the wave's 1 KB piece, then
 // global_load_lds_dwordx4): the compiler does not see an LDS write, so fragment reads through run-time selected buffer
 // pointers are not held back behind "vmcnt(0)" for a DMA they cannot alias (with the builtin that needs separately
@@ -323,6 +484,7 @@ __device__ __forceinline__ void attn2_dma16(const void* src, unsigned lds_byte_a
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
 }
 
+template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnParams p) {
   // tile images [stream][buffer][K | V]; afterwards the second stream's O passes through its images to the first stream
   __shared__ __attribute__((aligned(16))) u16 smem[2 * 2 * 2 * 4096];
@@ -362,6 +524,18 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnParams p) {
   for (int i = 0; i < 16; ++i) { oacc[0][0][i] = oacc[0][1][i] = oacc[1][0][i] = oacc[1][1][i] = 0.f; negm[0][i] = negm[1][i] = 0.f; }
   float mrun[2] = {0.f, 0.f}, lrun[2] = {0.f, 0.f};
   const int dblk = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+  // PIPE: chain 1's scores of the block in flight and the V fragments it still needs (attn3_block)
+  f32x16 ps1;
+  hx8 pva[2], pvb[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ps1[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { pva[0][j] = pva[1][j] = pvb[0][j] = pvb[1][j] = (h16)0.f; }
+#define ATTN2_BLOCK(FIRST_, TAIL_, CK, CV, KB, K0)                                                                          \
+  {                                                                                                                         \
+    if constexpr (PIPE) attn3_block<FIRST_, TAIL_>(CK, CV, KB, qf, oacc, negm, mrun, lrun, ps1, pva, pvb, K0, p.nkv, r, hh, dblk, tq, tp); \
+    else attn2_block<FIRST_, TAIL_>(CK, CV, KB, qf, oacc, negm, mrun, lrun, K0, p.nkv, r, hh, dblk, tq, tp);              \
+  }
 
   const int ntiles = (p.nkv + 63) / 64;
   const int nbar = (ntiles + 1) / 2;  // tiles of the first stream (the longer one): every wave runs nbar + 1 barriers
@@ -417,11 +591,11 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnParams p) {
       const u16* cV = cK + 4096;
       const int k0 = t0 * 64;
       if (k0 + 64 <= p.nkv) {
-        attn2_block<true, false>(cK, cV, 0, qf, oacc, negm, mrun, lrun, k0, p.nkv, r, hh, dblk, tq, tp);
-        attn2_block<false, false>(cK, cV, 1, qf, oacc, negm, mrun, lrun, k0 + 32, p.nkv, r, hh, dblk, tq, tp);
+        ATTN2_BLOCK(true, false, cK, cV, 0, k0);
+        ATTN2_BLOCK(false, false, cK, cV, 1, k0 + 32);
       } else {
-        attn2_block<true, true>(cK, cV, 0, qf, oacc, negm, mrun, lrun, k0, p.nkv, r, hh, dblk, tq, tp);
-        if (k0 + 32 < p.nkv) attn2_block<false, true>(cK, cV, 1, qf, oacc, negm, mrun, lrun, k0 + 32, p.nkv, r, hh, dblk, tq, tp);
+        ATTN2_BLOCK(true, true, cK, cV, 0, k0);
+        if (k0 + 32 < p.nkv) ATTN2_BLOCK(false, true, cK, cV, 1, k0 + 32);
       }
       ATTN2_END_TILE();
       done = 1;
@@ -434,22 +608,24 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnParams p) {
       if (tile + 1 < t1) stage(tile + 1, buf ^ 1);
       const u16* cK = sbase + buf * 8192;
       const u16* cV = cK + 4096;
-      attn2_block<false, false>(cK, cV, 0, qf, oacc, negm, mrun, lrun, tile * 64, p.nkv, r, hh, dblk, tq, tp);
-      attn2_block<false, false>(cK, cV, 1, qf, oacc, negm, mrun, lrun, tile * 64 + 32, p.nkv, r, hh, dblk, tq, tp);
+      ATTN2_BLOCK(false, false, cK, cV, 0, tile * 64);
+      ATTN2_BLOCK(false, false, cK, cV, 1, tile * 64 + 32);
       ATTN2_END_TILE();
     }
     if (tile < t1) {  // the partial last tile
       const u16* cK = sbase + (done & 1) * 8192;
       const u16* cV = cK + 4096;
       const int k0 = tile * 64;
-      attn2_block<false, true>(cK, cV, 0, qf, oacc, negm, mrun, lrun, k0, p.nkv, r, hh, dblk, tq, tp);
-      if (k0 + 32 < p.nkv) attn2_block<false, true>(cK, cV, 1, qf, oacc, negm, mrun, lrun, k0 + 32, p.nkv, r, hh, dblk, tq, tp);
+      ATTN2_BLOCK(false, true, cK, cV, 0, k0);
+      if (k0 + 32 < p.nkv) ATTN2_BLOCK(false, true, cK, cV, 1, k0 + 32);
       ATTN2_END_TILE();
       ++done;
     }
   }
+  if constexpr (PIPE) if (t1 > t0) attn3_drain(oacc, lrun, ps1, pva, pvb);
   for (; done < nbar; ++done) ATTN2_END_TILE();
 #undef ATTN2_END_TILE
+#undef ATTN2_BLOCK
 
   // merge: the second stream's waves hand (O, m, l) to the first stream's wave of the same rows, lane to lane, through the
   // second stream's tile images (every read of them is behind the loop's last barrier)
@@ -491,6 +667,288 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ 8-wave two-group kernel (round 3)
+// scratch/mb/coexec.hip on MI355X: two waves that share a SIMD and BOTH carry mixed MFMA + VALU streams cost the SUM of
+// their MFMA and VALU times (16 MFMAs + 128 VALU: 369 ns, against 256 + 151 alone), however the streams are interleaved;
+// an MFMA-only wave beside a VALU-only wave costs about the longer of the two (230 ns against 148 | 199).  attn64x2_kernel
+// is the first case.  This kernel makes it the second.  Block = 8 waves = two groups of four (waves w and w + 4 share a
+// SIMD: scratch/mb/hwid.hip); every wave alternates a MATRIX phase - O^T += V^T P^T of block i - 1, then S^T = K Q^T of
+// block i: 16 MFMAs out of registers, no LDS read, no vector work - with a VECTOR phase - the fragment reads of V (block i)
+// and K (block i + 1), mask / running maximum / exp2 / pack / row sums of block i: no MFMA - and group B runs one phase
+// behind group A; an s_barrier of all eight waves ends every phase, so that on every SIMD one wave's matrix phase always
+// faces the other's vector phase.
+// Work split: 128 query rows x 4 quarters of the key range; wave w = (row group w & 1, quarter w >> 1): group A sweeps
+// quarters 0 / 1, group B quarters 2 / 3.  A block = 32 keys; every quarter streams its blocks through a ring of four
+// 8 KB images [K | V] (LDS-DMA, each of the quarter's two waves brings half): 128 KB of LDS, one block per CU.  The DMA of
+// block i + 3 is issued at the end of matrix phase i (its image held block i - 1, whose last read was in vector phase
+// i - 1) and must have landed at the end of matrix phase i + 2: five phases.  (m, l, O) of the four quarters meet in the
+// LDS at the end.
+// Measured on the way here (s_memrealtime stamps per phase, 2 x 5 x 9216 x 9216): with the fragment reads at the start of
+// the matrix phase the 16 MFMAs took 380-410 ns to issue instead of 221 (LDS latency under load ~120 ns, and the phase
+// boundary is where all eight waves read at once); with 64-key tiles the eight DMA instructions of a tile cost their
+// wave ~170 ns of issue in one phase.
+__global__ __launch_bounds__(512, 2) void attn64pp_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];  // [quarter][ring slot][K | V] images of 32 keys; merge area afterwards
+  __shared__ float sML[3][2][2 * 64];                          // merge: m per (quarter 1..3, row group, chain) and lane
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 31, hh = lane >> 5;
+  const int rg = wv & 1, kq = wv >> 1, grp = wv >> 2;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = bid % p.nqt, bh = bid / p.nqt;
+  const int head = bh % p.heads, bz = bh / p.heads;
+  const u16* Q = p.q + (long long)bz * p.sq + head * 64;
+  const u16* K = p.k + (long long)bz * p.sk + head * 64;
+  const u16* V = p.v + (long long)bz * p.sv + head * 64;
+  u16* O = p.o + (long long)bz * p.so + head * 64;
+
+  hx8 qf[2][4];
+  int qrow[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qrow[qb] = qt * 128 + rg * 64 + qb * 32 + r;
+    const int qrc = qrow[qb] < p.nq ? qrow[qb] : p.nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const hx8 raw = *(const hx8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
+      if (p.scale_log2 == 1.0f) qf[qb][ks] = raw;
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (h16)((float)raw[j] * p.scale_log2);
+    }
+  }
+  const int spos = lane & 7;
+  u16* const sbase = smem + kq * 4 * 4096;  // this quarter's ring: 4 slots x (K 2048 | V 2048) u16
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) u16*)sbase + rg * 2048;  // bytes: this wave's 16 rows
+  // negm: a tile of -(running maximum), the C operand of every block's first S^T MFMA: the scores come out of the matrix
+  // phase already relative to the maximum (as in attn2_block)
+  f32x16 oacc[2][2], negm[2], sc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[0][0][i] = oacc[0][1][i] = oacc[1][0][i] = oacc[1][1][i] = 0.f; negm[0][i] = negm[1][i] = 0.f; sc[0][i] = sc[1][i] = 0.f; }
+  float mrun[2] = {0.f, 0.f}, lrun[2] = {0.f, 0.f};
+  const int dblk = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+
+  // key range of this quarter in 32-key blocks [b0, b0 + nb)
+  const int nblk = (p.nkv + 31) / 32;
+  const int nper = (nblk + 3) / 4;
+  const int b0 = min(nblk, kq * nper), nb = min(nblk, b0 + nper) - b0;
+  const int nphase_all = 2 * nper + 2;  // barriers every wave runs: start + group offset + 2 per block
+
+  // staging through buffer descriptors, 32-bit per-lane offsets (host: nkv * ld * 2 < 2^31).  The descriptors end with
+  // key nkv - 1: the rows of a partial last block past it arrive as ZEROS (scratch/mb/oob_lds.hip: a lane whose offset is
+  // out of range writes zeros through the LDS path too) - their scores are masked, and 0 x 0 keeps P.V finite.  Blocks
+  // past the quarter's end are "staged" with a descriptor of no records (zeros into a free slot): every matrix phase
+  // issues the same four DMA instructions, and vmcnt counts blocks.
+  unsigned offk[2], offv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * rg + 8 * j + (lane >> 3);
+    offk[j] = 2u * (row * p.ldk + (spos ^ ((row >> 1) & 7)) * 8);
+    offv[j] = 2u * (row * p.ldv + (spos ^ (((row >> 1) & 1) << 2)) * 8);
+  }
+  const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (p.nkv - 1) * p.ldk * 2 + 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (p.nkv - 1) * p.ldv * 2 + 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, 0, 0x00020000);
+  const int stepk = 64 * p.ldk, stepv = 64 * p.ldv;  // bytes per 32-key block
+  auto stage = [&](int i) {                          // block i of this quarter -> slot i & 3
+    const unsigned dst = lds0 + (i & 3) * 8192;
+    const bool live = i < nb;
+    const unsigned sk_ = (b0 + i) * stepk, sv_ = (b0 + i) * stepv;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      dma_buf16(live ? rsrcK : rsrcZ, offk[j] + sk_, 0, dst + j * 1024);
+      dma_buf16(live ? rsrcV : rsrcZ, offv[j] + sv_, 0, dst + 4096 + j * 1024);
+    }
+  };
+  // every phase ends here: this wave's LDS reads are complete, then all eight waves meet.  MX: a matrix phase ends - (a) the
+  // DMA of the block whose K the next vector phase reads has landed: all but the two youngest stages (8 instructions);
+  // (b) the MFMAs are asm statements, which the compiler's hazard recognizer does not see into: the s_nops cover the wait
+  // states between an MFMA's last pass and a vector read of its result (every vector read of sc / oacc is behind such a
+  // barrier)
+#define PP_BAR(MX)                                                                                    \
+  {                                                                                                   \
+    if (MX) __builtin_amdgcn_s_waitcnt(0x0078); /* vmcnt(8) lgkmcnt(0) */                             \
+    else __builtin_amdgcn_s_waitcnt(0xC07F);    /* lgkmcnt(0) */                                      \
+    if (MX) asm volatile("s_nop 15\n\ts_nop 3");                                                      \
+    __builtin_amdgcn_sched_barrier(0); /* nothing drifts into the other kind of phase */              \
+    asm volatile("" ::: "memory");                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                     \
+    asm volatile("" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+  hx8 kf[4], vf[2][2];
+  A3P pb[2][2];  // P of the block in flight: [chain][keys 0-15 | 16-31]
+#define PP_READ_K(I)                                                                                         \
+  {                                                                                                          \
+    const u16* cK = sbase + ((I) & 3) * 4096;                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const hx8*)&cK[k_off(r, 2 * ks + hh)];       \
+  }
+#define PP_READ_V(I)                                                                                         \
+  {                                                                                                          \
+    const u16* cV = sbase + ((I) & 3) * 4096 + 2048;                                                         \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                         \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) vf[s2][dt] = a3_vfrag(cV, 0, s2, dt, hh, dblk, tq, tp); \
+  }
+  // the MFMAs as asm statements with the accumulator tied in place: with the builtin the register allocator is free to put
+  // an MFMA's result beside its C operand, and under this loop's pressure it does (a second copy of O^T, v_mov_b64 trains)
+#define PP_MFMA(ACC, A, B) asm volatile(MFMA32_MNEMONIC " %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define PP_MFMA0(D, A, B, C_) asm volatile(MFMA32_MNEMONIC " %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C_))
+#define PP_PV()                                                                                              \
+  {                                                                                                          \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                         \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                       \
+        _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) PP_MFMA(oacc[qb][dt], vf[s2][dt], pb[qb][s2].v);    \
+  }
+#define PP_QK()                                                                                              \
+  {                                                                                                          \
+    PP_MFMA0(sc[0], kf[0], qf[0][0], negm[0]);                                                               \
+    PP_MFMA0(sc[1], kf[0], qf[1][0], negm[1]);                                                               \
+    _Pragma("unroll") for (int ks = 1; ks < 4; ++ks)                                                         \
+      _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) PP_MFMA(sc[qb], kf[ks], qf[qb][ks]);                  \
+  }
+  // vector phase of block i.  Its results - and the fragments it has read for the next matrix phase - are "used" at its
+  // end: without that LLVM sinks half of the exponentials below the barrier, into the matrix phase (they are needed only
+  // there).  (With both a masked and an unmasked softmax body inside the loop the register allocator ran out - 256 VGPRs,
+  // spills and 64 v_mov_b64 per block: the masked block stands outside the loop.)
+#define PP_SOFTMAX(FIRST_, TAIL_, I)                                                                         \
+  {                                                                                                          \
+    PP_READ_V(I);                                                                                            \
+    if ((I) + 1 < nb) PP_READ_K((I) + 1);                                                                    \
+    const int key0 = (b0 + (I)) * 32;                                                                        \
+    _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                       \
+      a3_mask<TAIL_>(sc[qb], key0, p.nkv, hh);                                                               \
+      a3_max<FIRST_>(sc[qb], oacc[qb], negm[qb], mrun[qb], lrun[qb]);                                        \
+      A3_E2(sc[qb], 0, pb[qb][0].h[0], lrun[qb]); A3_E2(sc[qb], 1, pb[qb][0].h[1], lrun[qb]);                \
+      A3_E2(sc[qb], 2, pb[qb][0].h[2], lrun[qb]); A3_E2(sc[qb], 3, pb[qb][0].h[3], lrun[qb]);                \
+      A3_E2(sc[qb], 4, pb[qb][1].h[0], lrun[qb]); A3_E2(sc[qb], 5, pb[qb][1].h[1], lrun[qb]);                \
+      A3_E2(sc[qb], 6, pb[qb][1].h[2], lrun[qb]); A3_E2(sc[qb], 7, pb[qb][1].h[3], lrun[qb]);                \
+    }                                                                                                        \
+    _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                                         \
+      asm volatile("" : "+v"(pb[qb][0].v), "+v"(pb[qb][1].v), "+v"(negm[qb]), "+v"(lrun[qb]), "+v"(oacc[qb][0]), "+v"(oacc[qb][1])); \
+    asm volatile("" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));                        \
+    asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));                                   \
+  }
+
+  stage(0); stage(1); stage(2);
+  __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+  PP_BAR(false);
+  int bars = 1;
+  if (grp) { PP_BAR(false); ++bars; }  // group B runs one phase behind
+  if (nb > 0) {
+    const bool last_partial = (p.nkv & 31) != 0 && b0 + nb == nblk;  // the quarter's last block holds keys past nkv
+    // block 0: its K fragments are read here, S^T only
+    PP_READ_K(0);
+    PP_QK();
+    stage(3);
+    PP_BAR(true); ++bars;
+    if (nb == 1 && last_partial) PP_SOFTMAX(true, true, 0) else PP_SOFTMAX(true, false, 0)
+    PP_BAR(false); ++bars;
+  // the 16 MFMAs of a matrix phase in an order that reuses no accumulator within four instructions (one wave alone does
+  // not fill the pipe with dependent pairs: 17.3 ns per MFMA against 13.8), the four DMA instructions of block i + 3 spread
+  // between them (issued together they wait for the address unit: ~100 ns at the end of the phase)
+#define PP_BLOCK(TAIL_, I)                                                                                   \
+  {                                                                                                          \
+    const unsigned dst_ = lds0 + (((I) + 3) & 3) * 8192;                                                     \
+    const bool live_ = (I) + 3 < nb;                                                                         \
+    const unsigned sk_ = (b0 + (I) + 3) * stepk, sv_ = (b0 + (I) + 3) * stepv;                               \
+    PP_MFMA0(sc[0], kf[0], qf[0][0], negm[0]);                                                               \
+    PP_MFMA0(sc[1], kf[0], qf[1][0], negm[1]);                                                               \
+    PP_MFMA(oacc[0][0], vf[0][0], pb[0][0].v);                                                               \
+    PP_MFMA(oacc[1][0], vf[0][0], pb[1][0].v);                                                               \
+    dma_buf16(live_ ? rsrcK : rsrcZ, offk[0] + sk_, 0, dst_);                                                \
+    PP_MFMA(sc[0], kf[1], qf[0][1]);                                                                         \
+    PP_MFMA(sc[1], kf[1], qf[1][1]);                                                                         \
+    PP_MFMA(oacc[0][1], vf[0][1], pb[0][0].v);                                                               \
+    PP_MFMA(oacc[1][1], vf[0][1], pb[1][0].v);                                                               \
+    dma_buf16(live_ ? rsrcV : rsrcZ, offv[0] + sv_, 0, dst_ + 4096);                                         \
+    PP_MFMA(sc[0], kf[2], qf[0][2]);                                                                         \
+    PP_MFMA(sc[1], kf[2], qf[1][2]);                                                                         \
+    PP_MFMA(oacc[0][0], vf[1][0], pb[0][1].v);                                                               \
+    PP_MFMA(oacc[1][0], vf[1][0], pb[1][1].v);                                                               \
+    dma_buf16(live_ ? rsrcK : rsrcZ, offk[1] + sk_, 0, dst_ + 1024);                                         \
+    PP_MFMA(sc[0], kf[3], qf[0][3]);                                                                         \
+    PP_MFMA(sc[1], kf[3], qf[1][3]);                                                                         \
+    PP_MFMA(oacc[0][1], vf[1][1], pb[0][1].v);                                                               \
+    PP_MFMA(oacc[1][1], vf[1][1], pb[1][1].v);                                                               \
+    dma_buf16(live_ ? rsrcV : rsrcZ, offv[1] + sv_, 0, dst_ + 4096 + 1024);                                  \
+    PP_BAR(true); ++bars;                                                                                    \
+    PP_SOFTMAX(false, TAIL_, I)                                                                              \
+    PP_BAR(false); ++bars;                                                                                   \
+  }
+    const int nloop = (last_partial && nb > 1) ? nb - 1 : nb;
+    for (int i = 1; i < nloop; ++i) PP_BLOCK(false, i)
+    if (nloop < nb) PP_BLOCK(true, nb - 1)
+#undef PP_BLOCK
+    PP_PV();  // the last block's P.V
+  }
+  for (; bars < nphase_all; ++bars) PP_BAR(false);
+  __builtin_amdgcn_s_waitcnt(0x0070);  // the stages past the end have landed before the ring becomes the merge area
+  __syncthreads();
+#undef PP_READ_K
+#undef PP_PV
+#undef PP_QK
+#undef PP_READ_V
+#undef PP_SOFTMAX
+#undef PP_MFMA
+#undef PP_MFMA0
+
+  // merge: quarters 1 - 3 hand (O, m, l) to quarter 0's wave of the same rows, lane to lane, through the tile images
+  // (every read of them is behind the last barrier)
+  float* mgO = (float*)smem;  // [quarter - 1][row group][64 accumulator registers][64 lanes]: 3 x 2 x 16 KB
+  if (kq > 0) {
+    float* o_ = mgO + ((kq - 1) * 2 + rg) * 4096;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o_[((qb * 2 + dt) * 16 + i) * 64 + lane] = oacc[qb][dt][i];
+      sML[kq - 1][rg][qb * 64 + lane] = nb > 0 ? mrun[qb] : -3.0e38f;  // a quarter without keys weighs nothing
+    }
+  }
+  // l travels in a second pass through the same words' neighbours: keep it simple - a separate array in the merge area
+  float* mgL = mgO + 3 * 2 * 4096;  // [quarter - 1][row group][chain][lane]
+  if (kq > 0) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) mgL[(((kq - 1) * 2 + rg) * 2 + qb) * 64 + lane] = lrun[qb];
+  }
+  __syncthreads();
+  if (kq > 0) return;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float mq[3], lq[3];
+    float m = nb > 0 ? mrun[qb] : -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      mq[q] = sML[q][rg][qb * 64 + lane];
+      lq[q] = mgL[((q * 2 + rg) * 2 + qb) * 64 + lane];
+      m = fmaxf(m, mq[q]);
+    }
+    const float a0 = nb > 0 ? __builtin_amdgcn_exp2f(mrun[qb] - m) : 0.f;
+    float aq[3];
+    float lsum = lrun[qb] * a0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { aq[q] = __builtin_amdgcn_exp2f(mq[q] - m); lsum += lq[q] * aq[q]; }
+    const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
+    if (qrow[qb] < p.nq) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = 32 * dt + 8 * g + 4 * hh;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float acc = oacc[qb][dt][4 * g + e] * a0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc += mgO[(q * 2 + rg) * 4096 + ((qb * 2 + dt) * 16 + 4 * g + e) * 64 + lane] * aq[q];
+            o[e] = acc * inv;
+          }
+          *(uint2*)(O + (long long)qrow[qb] * p.ldo + d) = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
+        }
+    }
+  }
+#undef PP_BAR
+}
+
 static int attention_launch(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v, int ldv,
                             int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv, float scale,
                             bool log2q, void* stream) {
@@ -512,7 +970,24 @@ static int attention_launch(const void* q, int ldq, int64_t sq, const void* k, i
   const int min_nq = sdmi_opt(OPT_attn_x2_min_nq);
   if (variant > 0 || (variant == 0 && nkv >= 1024 && nq >= (min_nq > 0 ? min_nq : 2048))) {
     p.nqt = (nq + 127) / 128; p.heads = heads;
-    hipLaunchKernelGGL(attn64x2_kernel, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
+    // two-group 8-wave kernel: on request only (attn_pp = 1) - it does not beat attn64x2_kernel
+    const bool pp_ok = (long long)nkv * ldk * 2 < (1ll << 31) && (long long)nkv * ldv * 2 < (1ll << 31);  // 32-bit K / V offsets
+    if (pp_ok && sdmi_opt(OPT_attn_pp) > 0) {
+      constexpr int bytes = 4 * 2 * 2 * 4096 * 2;  // 128 KB
+      static unsigned long long attr_done = 0;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (!((attr_done >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute((const void*)attn64pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_done |= 1ull << (dev & 63);
+      }
+      hipLaunchKernelGGL(attn64pp_kernel, dim3(p.nqt * heads * batch), dim3(512), bytes, (hipStream_t)stream, p);
+      sdmi_note_kernel("attn64pp_kernel");
+      return sdmi_check_launch("attention (two wave groups)");
+    }
+    // attn_pipe_off = 1: the lockstep block of round 2 (A/B switch; same bits)
+    if (sdmi_opt(OPT_attn_pipe_off)) hipLaunchKernelGGL(attn64x2_kernel<false>, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn64x2_kernel<true>, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
     sdmi_note_kernel("attn64x2_kernel");
     return sdmi_check_launch("attention (64 rows per wave)");
   }

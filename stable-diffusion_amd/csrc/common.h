@@ -51,7 +51,8 @@ void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the 
   X(attn_x2_min_nq, 0, "> 0: query rows from which long self-attention takes the 64-rows-per-wave kernel (default 2048)")                        \
   X(attn_variant, 0, "attention kernel variant (0 = default)")                                                                                   \
   X(gemm_buf_off, 0, "1: GEMMs stage with the round-2 pointer-per-lane loader instead of buffer descriptors, A/B switch")                         \
-  X(conv_win_var, 0, "experiment variant of conv_win2_kernel (template VAR)")                                                                     \
+  X(attn_pipe_off, 0, "1: long self-attention with the lockstep block of round 2 instead of the software-pipelined one, A/B switch")             \
+  X(attn_pp, 0, "1: long self-attention on the two-group 8-wave kernel attn64pp_kernel (not faster: DESIGN.md, round 3)")                           \
   X(conv_win_v1, 0, "1: shared-window convs on the round-2 kernel (global_load_lds + per-lane pointers), A/B switch")
 enum SdmiOpt {
 #define SDMI_OPT_ENUM(name, def, doc) OPT_##name,
@@ -112,4 +113,15 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   const int q = nb >> 3, r = nb & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// ---- LDS-DMA through a buffer descriptor (igemm.hip, attention.hip)
+constexpr unsigned DMA_OOB = 0x80000000u;  // voffset of a lane that must fetch zeros (>= num_records of every descriptor here)
+// one LDS-DMA wave-instruction: 64 lanes x 16 B -> 1 KB of LDS at byte address `lds` (wave-uniform); not counted by the
+// compiler (inline asm): the loops wait with their own s_waitcnt vmcnt
+__device__ __forceinline__ void dma_buf16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* smem_ptr) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem_ptr;
 }

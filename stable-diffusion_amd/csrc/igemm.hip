@@ -576,16 +576,6 @@ __device__ __forceinline__ void igemm_finish(const IgemmParams& p, f32x4 (&acc)[
   }
 }
 
-constexpr unsigned DMA_OOB = 0x80000000u;  // voffset of a lane that must fetch zeros (>= num_records of every descriptor here)
-// one LDS-DMA wave-instruction: 64 lanes x 16 B -> 1 KB of LDS at byte address `lds` (wave-uniform); not counted by the
-// compiler (inline asm): the loops wait with their own s_waitcnt vmcnt
-__device__ __forceinline__ void dma_buf16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* smem_ptr) {
-  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem_ptr;
-}
-
 // The second launch bound (2 waves per SIMD for the 4-wave tiles = the 256-register budget they run at anyway) matters:
 // with the default 512-register budget hipcc split the accumulators over VGPRs and AGPRs and shuffled them with 74
 // v_accvgpr moves per K-tile in the plain-GEMM instantiations (MFMA not accumulating in place).
@@ -1245,9 +1235,9 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(const IgemmParams p) {
 // Same K order, same arithmetic, same epilogue as conv_win_kernel and igemm_kernel: same bits (tested).
 // Needs Cin % 64 == 0 and panels below 2 GB (host); everything else keeps conv_win_kernel.
 __device__ __forceinline__ int lds_off_w(int row, int chunk) { return row * BK + ((chunk ^ (((row >> 1) & 3) << 1)) << 3); }
-// VAR (experiments, conv_win_var option): bit 0 = scheduling fences that keep a step's fragment reads in front of the previous
-// step's MFMAs (the compiler otherwise sinks them to their first use), bit 1 = s_setprio around the MFMA batches
-template <int BM, int BN, bool CS, int VAR = 0>
+// (Tried and dropped, profiles/r03_conv_win2_ab.txt: scheduling fences that keep a step's fragment reads in front of the
+// previous step's MFMAs, and s_setprio around the MFMA batches - 178 VGPRs instead of 154, 1.5 ... 4 % slower.)
+template <int BM, int BN, bool CS>
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_win2_kernel(const IgemmParams p) {
   constexpr int TM = BM / 2, TN = BN / 2, MT = TM / 16, NT = TN / 16;
   constexpr int WROWS = BM + 8;           // staged window rows: BM + 2 are read; whole 8-row DMA instructions
@@ -1346,15 +1336,11 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_win2_kernel(const 
     const u16* cB = bring + (SLOT) * BSLOT;                                                                         \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) AF[i] = *(const hx8*)&(WB)[aoff[i][KX] ^ ((KK) ? 32 : 0)];       \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const hx8*)&cB[boff[j] ^ ((KK) ? 32 : 0)];             \
-    if constexpr (VAR & 1) __builtin_amdgcn_sched_barrier(0);                                                       \
   }
 #define WIN2_MFMA(AF, WF)                                                                                  \
   {                                                                                                        \
-    if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);                                                  \
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                         \
       _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(WF[j], AF[i], acc[i][j], 0, 0, 0); \
-    if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);                                                  \
-    if constexpr (VAR & 1) __builtin_amdgcn_sched_barrier(0);                                              \
   }
 
   f32x4 acc[MT][NT];
@@ -1649,10 +1635,10 @@ static void stats_parts_of(const IgemmParams& p, int batch, int vi, int* row_par
   if (col_parts) *col_parts = (plain && p.N % 32 == 0) ? p.N / 32 : 0;
 }
 
-// conv_win2_kernel launch: instantiation by (statistics, experiment variant); > 64 KB of dynamic LDS allowed once per device
-template <int BM, int BN, bool CS, int VAR>
-static void launch_win2_v(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
-  auto kfn = conv_win2_kernel<BM, BN, CS, VAR>;
+// conv_win2_kernel launch; > 64 KB of dynamic LDS allowed once per device
+template <int BM, int BN, bool CS>
+static void launch_win2_cs(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
+  auto kfn = conv_win2_kernel<BM, BN, CS>;
   static unsigned long long attr_done = 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1664,17 +1650,8 @@ static void launch_win2_v(dim3 grid, int bytes, hipStream_t st, const IgemmParam
 }
 template <int BM, int BN>
 static void launch_win2(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
-  const int var = sdmi_opt(OPT_conv_win_var);
-#define WIN2_CASE(V)                                                        \
-  case V:                                                                   \
-    if (p.colstats) launch_win2_v<BM, BN, true, V>(grid, bytes, st, p);     \
-    else launch_win2_v<BM, BN, false, V>(grid, bytes, st, p);               \
-    break;
-  switch (var) {
-    WIN2_CASE(1) WIN2_CASE(2) WIN2_CASE(3)
-    default: WIN2_CASE(0)
-  }
-#undef WIN2_CASE
+  if (p.colstats) launch_win2_cs<BM, BN, true>(grid, bytes, st, p);
+  else launch_win2_cs<BM, BN, false>(grid, bytes, st, p);
 }
 
 template <bool CONV>

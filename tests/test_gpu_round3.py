@@ -254,3 +254,84 @@ def test_range_audit_reports_clipped_vae_layers():
     assert len(E.RANGE_LOG) >= 1 and E.RANGE_LOG[0][0].startswith("conv") and E.RANGE_LOG[0][3] > 0
     assert torch.isfinite(ok).all() and torch.isfinite(big).all()      # saturation, not inf / NaN (GroupNorm renormalises)
     E.RANGE_LOG.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# attn64pp_kernel (8 waves, two groups, four key quarters; opt-in through the attn_pp option - it does not beat
+# attn64x2_kernel): quarters without keys, one key, a partial last block (zero-filled through the
+# descriptor's range check and masked), rows past nq, running-maximum moves early / late in a quarter, wide logits.
+def _attn_ref(q, k, v, heads, scale=0.125):
+    b, nq, c = q.shape
+    sp = lambda t: t.double().reshape(b, t.shape[1], heads, 64).permute(0, 2, 1, 3)
+    a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * scale, dim=-1) @ sp(v)
+    return a.permute(0, 2, 1, 3).reshape(b, nq, c)
+
+
+@pytest.fixture
+def attn_opts():
+    lib = L.load()
+    def set_(variant, pp):
+        lib.sdmi_set_option(b"attn_variant", variant)
+        lib.sdmi_set_option(b"attn_pp", pp)
+    yield set_
+    set_(0, 0)
+
+
+@pytest.mark.parametrize("b,heads,nq,nkv,kind", [
+    (1, 1, 64, 1, "plain"),         # one key: three quarters empty
+    (1, 1, 64, 31, "plain"),        # one partial block
+    (1, 2, 130, 64, "plain"),       # one full tile
+    (1, 2, 130, 65, "plain"),       # second quarter = one key
+    (2, 3, 257, 77, "plain"),       # the cross-attention shape, rows past nq
+    (1, 2, 300, 257, "plain"),      # 5 tiles: quarters of 2, 2, 1 (one key) and 0 tiles
+    (1, 2, 200, 480, "plain"),      # 8 tiles: the last one holds 32 keys (an odd number of blocks)
+    (1, 2, 1000, 1111, "plain"),
+    (1, 2, 512, 640, "late_spike"),
+    (1, 2, 512, 640, "early_spike"),
+    (1, 2, 2304, 2304, "wide"),     # logits of about +-200
+    (2, 5, 2304, 2304, "plain"),
+    (1, 1, 4096, 4097, "plain"),
+])
+def test_attention_two_group_kernel_vs_fp64(attn_opts, b, heads, nq, nkv, kind):
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(nq * 7 + nkv)
+    c = heads * 64
+    q, k, v = (torch.randn(b, n, c, generator=g).to(dev) for n in (nq, nkv, nkv))
+    if kind == "late_spike":
+        k[:, 600] = q[:, 7] * 3.0
+    if kind == "early_spike":
+        k[:, 3] = q[:, 7] * 3.0
+    if kind == "wide":
+        q *= 5.0
+        k *= 5.0
+    H = E.act_dtype()
+    mk = lambda t: E.Act(t.contiguous(), t.shape[0], 1, t.shape[1], t.shape[2])
+    qh, kh, vh = q.to(H), k.to(H), v.to(H)
+    ql = (q * E.Q_LOG2_SCALE).to(H)
+    want = _attn_ref(qh, kh, vh, heads)
+    want_l = _attn_ref(ql.double() / E.Q_LOG2_SCALE, kh, vh, heads)
+    outs = {}
+    for pp in (-1, 1):
+        attn_opts(1, pp)
+        outs[pp] = E.attention(mk(qh), mk(kh), mk(vh), heads).buf.double()
+        outs[pp, "l"] = E.attention(mk(ql), mk(kh), mk(vh), heads, log2q=True).buf.double()
+        assert L.load().sdmi_last_kernel().decode() == ("attn64pp_kernel" if pp == 1 else "attn64x2_kernel")
+    l2 = lambda a, b_: float((a - b_).norm() / b_.norm())
+    gate = 6e-4 * _tol()                         # the gate of sdmi_attention everywhere else (fp16 P and V roundings)
+    print("two-group kernel %s nq %d nkv %d: rel-L2 vs fp64 %.2e (log2q) %.2e (scale path); 64-row kernel %.2e" %
+          (kind, nq, nkv, l2(outs[1, "l"], want_l), l2(outs[1], want), l2(outs[-1, "l"], want_l)))
+    assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[1, "l"]).all()
+    assert l2(outs[1, "l"], want_l) < gate
+    assert l2(outs[1, "l"], outs[-1, "l"]) < gate
+    assert l2(outs[1], want) < (gate if kind != "wide" else 2.5e-3 * _tol())
+
+
+def test_attention_two_group_kernel_is_opt_in(attn_opts):
+    H = E.act_dtype()
+    t = torch.randn(1, 2304, 128, device=DEV).to(H)
+    a = E.Act(t, 1, 1, 2304, 128)
+    E.attention(a, a, a, 2, log2q=True)
+    assert L.load().sdmi_last_kernel().decode() == "attn64x2_kernel"
+    attn_opts(0, 1)
+    E.attention(a, a, a, 2, log2q=True)
+    assert L.load().sdmi_last_kernel().decode() == "attn64pp_kernel"
