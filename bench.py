@@ -41,7 +41,7 @@ DECODE_GFLOP = {64: 2514.5, 96: 5754.3, 128: 10470.4}
 def work_of(name, a):
     """(algorithmic flops, algorithmic bytes) of one C-ABI call from its arguments (see include/sdmi.h).  `name` is the
     kernel symbol for conv/gemm/attention calls (sdmi_last_kernel), the entry point otherwise."""
-    if name.startswith("conv_win_kernel") or (name.startswith("igemm_kernel") and "true," in name):
+    if name.startswith("conv_win") or (name.startswith("igemm_kernel") and "true," in name):
         n, cin, cout, ho, wo = a[2], a[5], a[7], a[8], a[9]
         return 2.0 * n * ho * wo * cout * 9 * cin, 2.0 * (n * a[3] * a[4] * cin + n * ho * wo * cout + 9 * cin * cout)
     if name.startswith("igemm_kernel"):
@@ -238,14 +238,17 @@ def main():
         return {"mfma_tflops": mfma, "hbm_copy_gbs": hbm}
 
     roof, kernels = None, None
-    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r02_traffic.json", "r01_traffic.json"))
+    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"))
                          if os.path.exists(f)), None)
     pmc_traffic = json.load(open(traffic_file)) if traffic_file else {}
 
     def traffic_of(kernel):
         """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md
         HBM section), weighted like `achieved`: ddim_steps x the UNet-step launches + the decode launches."""
-        e = pmc_traffic.get("kernels", {}).get(kernel)
+        ks = pmc_traffic.get("kernels", {})
+        # (the profiler prints the GEMM kernels with their last template argument - the staging variant - which the
+        # library's own kernel note leaves out)
+        e = ks.get(kernel) or next((v for k, v in ks.items() if k.startswith(kernel[:-1] + ",")), None)
         if not e or pmc_traffic.get("resolution") != args.res:
             return None
         byt = args.ddim_steps * e["unet"]["bytes"] + e["decode"]["bytes"]
@@ -338,7 +341,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
             "kernels_note": "HIP-event pairs around every C-ABI launch of ONE eager batch-%d UNet step (x%d) + one decode on one "
                             "stream; a ranking, not an accounting of the graph-replayed two-stream loop (rocprofv3 window of "
-                            "the same pass: profiles/r02_roofline_pass_kernel_stats.csv)" % (2 * b, args.ddim_steps),
+                            "the same pass: profiles/r03_roofline_pass_kernel_stats.csv)" % (2 * b, args.ddim_steps),
         }
         print(json.dumps(line))
     if use_dist:

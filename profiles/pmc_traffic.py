@@ -1,4 +1,4 @@
-"""Turn the two rocprofv3 PMC passes of `bench.py --pmc-workload` into profiles/rNN_traffic.json (4th argument, default profiles/r02_traffic.json).
+"""Turn the two rocprofv3 PMC passes of `bench.py --pmc-workload` into profiles/rNN_traffic.json (4th argument, default profiles/r03_traffic.json).
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --pmc-workload ...
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --pmc-workload ...
@@ -43,7 +43,7 @@ def main():
             e["bytes"] = e["fetch_bytes_x2"] + e["write_bytes"]
     res = int(sys.argv[3]) if len(sys.argv) > 3 else 768
     json.dump({"resolution": res, "note": "HBM-side bytes per kernel over one UNet step (CFG batch 2) and one decode: 2 x FETCH_SIZE + WRITE_SIZE, "
-               "separate rocprofv3 --pmc passes of `bench.py --pmc-workload`", "kernels": out}, open(sys.argv[4] if len(sys.argv) > 4 else "profiles/r02_traffic.json", "w"), indent=1)
+               "separate rocprofv3 --pmc passes of `bench.py --pmc-workload`", "kernels": out}, open(sys.argv[4] if len(sys.argv) > 4 else "profiles/r03_traffic.json", "w"), indent=1)
     for k, e in sorted(out.items(), key=lambda kv: -(50 * kv[1]["unet"]["bytes"] + kv[1]["decode"]["bytes"]))[:12]:
         n = 50 * e["unet"]["launches"] + e["decode"]["launches"]
         print("%-60s %9.2f MB / launch (weighted 50 x UNet + decode, %d launches)" % (k, (50 * e["unet"]["bytes"] + e["decode"]["bytes"]) / n / 1e6, n))
