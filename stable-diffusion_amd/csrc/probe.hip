@@ -3,26 +3,30 @@
 // calls them.
 #include "common.h"
 
-// Back-to-back v_mfma_f32_32x32x16 on two accumulator chains, 8 waves per CU (two per SIMD): the matrix-pipe issue
-// rate, nothing else (no memory, no LDS).  2 * 32 * 32 * 16 flop per MFMA and wave.
+// Back-to-back v_mfma_f32_32x32x16 on FOUR independent accumulator chains, 8 waves per CU (two per SIMD): the matrix-pipe
+// issue rate, nothing else (no memory, no LDS).  2 * 32 * 32 * 16 flop per MFMA and wave.  (Rounds 1-2 ran two chains per
+// wave and read 1.89-1.92 PFLOP/s: dependent pairs do not fill the pipe - 17.3 ns per MFMA against 13.8; four chains
+// sustain 2.38-2.43, scratch/mb/mfma_peak.hip.)
 __global__ __launch_bounds__(256) void probe_mfma_kernel(float* out, int iters) {
   const int lane = threadIdx.x;
   hx8 a, b;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a[j] = (h16)(0.001f * lane + j); b[j] = (h16)(0.002f * lane - j); }
-  f32x16 acc0, acc1;
+  f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       acc0 = MFMA32(a, b, acc0, 0, 0, 0);
       acc1 = MFMA32(a, b, acc1, 0, 0, 0);
+      acc2 = MFMA32(a, b, acc2, 0, 0, 0);
+      acc3 = MFMA32(a, b, acc3, 0, 0, 0);
     }
   }
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+  for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i] + acc2[i] + acc3[i];
   if (s == 12345.678f) out[0] = s;  // keeps the loop alive, never true
 }
 
