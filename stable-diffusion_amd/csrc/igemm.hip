@@ -1238,7 +1238,7 @@ __device__ __forceinline__ int lds_off_w(int row, int chunk) { return row * BK +
 // (Tried and dropped, profiles/r03_conv_win2_ab.txt: scheduling fences that keep a step's fragment reads in front of the
 // previous step's MFMAs, and s_setprio around the MFMA batches - 178 VGPRs instead of 154, 1.5 ... 4 % slower.)
 template <int BM, int BN, bool CS>
-__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_win2_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_win2_kernel(const IgemmParams p) {
   constexpr int TM = BM / 2, TN = BN / 2, MT = TM / 16, NT = TN / 16;
   constexpr int WROWS = BM + 8;           // staged window rows: BM + 2 are read; whole 8-row DMA instructions
   constexpr int WBUF = (WROWS + 1) * BK;  // elements per window buffer, + one row of zeros
@@ -1498,7 +1498,12 @@ static const TileVariant kVariants[] = {
     {64, 64, 2, 2, 5},    // 5: 80 KB, 2 blocks / CU, 4 K-tiles in flight
     {128, 64, 2, 2, 3},   // 6: 72 KB, 2 blocks / CU
     {64, 128, 2, 2, 4},   // 7: 96 KB, 1 block / CU
+    // shared-window conv only (conv_win2_kernel<256, 128>): 4 waves x (128 x 64) - twelve fragment reads per 32 MFMAs instead
+    // of eight per 16 (a 64 x 64 wave tile reads 128 B of LDS per clock and CU at full MFMA rate: the LDS's whole bandwidth),
+    // 100 KB of LDS, one block per CU, one wave per SIMD (up to 512 VGPRs)
+    {256, 128, 2, 2, 2},  // 8
 };
+constexpr int VI_WIN256 = 8;
 
 template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, bool GEGLU, bool BUF = false>
 static void launch_variant2(dim3 grid, hipStream_t st, const IgemmParams& p) {
@@ -1567,6 +1572,15 @@ static int variant_blocks_per_cu(const TileVariant& tv, bool ln) {
 
 // Tile choice.  The main loop is bound by the L2 -> LDS path (about 70 GB/s per CU), so the biggest tile that still
 // gives every CU a block wins; SDMI_IGEMM_TILE=<index into kVariants> forces one (experiments).
+// what the shared-window conv kernels need (stride 1, pad 1, same size, no upsampling; v2: whole 64-channel chunks, 32-bit
+// panel offsets)
+static bool conv_window_shape(const IgemmParams& p, int batch) {
+  return p.stride == 1 && !p.ups && p.pad_t == 1 && p.pad_l == 1 && p.Ho == p.H && p.Wo == p.W && batch == 1;
+}
+static bool conv_win2_ok(const IgemmParams& p, int bm) {
+  return !sdmi_opt(OPT_conv_win_v1) && p.Cin % 64 == 0 && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
+         ((long long)(bm + 16) + 2 * p.W) * p.lda * 2 + 2 * p.Cin < (1ll << 31);
+}
 static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   static int forced = -2;
   if (forced == -2) {
@@ -1600,6 +1614,11 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   static const int bm128_min = [] { const char* e = getenv("SDMI_BM128_MIN"); return e ? atoi(e) : 128; }();
   const int opt_bm = sdmi_opt(OPT_bm128_min);
   const bool bm128 = p.M > 64 && tiles128 >= (opt_bm > 0 ? opt_bm : bm128_min);
+  // 256 x 128 window tiles (4 waves x 128 x 64: 1.5 fragment reads per 4 MFMAs instead of 2): opt-in (conv_win_256 = 1).
+  // The same loop at one block per CU and one wave per SIMD is 13-38 % SLOWER on the VAE's levels and 17-24 % at batch 4
+  // (profiles/r03_conv_win256_ab.txt; same bits): what a larger wave tile saves in LDS reads it loses to the waits a lone
+  // wave per SIMD cannot hide - round 2's 8-wave 256 x 128 GEMM variant lost the same way.
+  if (conv && bn128 && p.N % 128 == 0 && sdmi_opt(OPT_conv_win_256) > 0 && conv_window_shape(p, batch) && conv_win2_ok(p, 256)) return VI_WIN256;
   if (bm128 && bn128) return 1;
   if (bm128) return 2;
   if (bn128) return 3;
@@ -1715,13 +1734,19 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     static int win_env = -1;
     if (win_env < 0) { const char* e = getenv("SDMI_CONV_WIN"); win_env = (e && e[0] == '0') ? 0 : 1; }
     const int win_ok = g_force_window >= 0 ? g_force_window : win_env;
-    if (win_ok && (vi == 1 || vi == 2) && p.stride == 1 && !p.ups && p.pad_t == 1 && p.pad_l == 1 && p.Ho == p.H && p.Wo == p.W && batch == 1) {
+    if (vi == VI_WIN256 && !(win_ok && conv_window_shape(p, batch) && conv_win2_ok(p, 256) && p.N % 128 == 0)) {
+      sdmi_set_error("conv3x3: tile variant %d runs stride-1 pad-1 convs with Cin %% 64 == 0 and Cout %% 128 == 0 only", vi);
+      return SDMI_EINVAL;
+    }
+    if (win_ok && (vi == 1 || vi == 2 || vi == VI_WIN256) && conv_window_shape(p, batch)) {
       constexpr int wbytes128 = (2 * (128 + 8 + 1) * BK + 2 * 128 * BK) * 2, wbytes64 = (2 * (128 + 8 + 1) * BK + 2 * 64 * BK) * 2;
+      constexpr int wbytes256 = (2 * (256 + 8 + 1) * BK + 2 * 128 * BK) * 2;
       // round-3 kernel (buffer-descriptor staging, shift-proof swizzle) wherever its preconditions hold; conv_win_v1 = 1
       // keeps the round-2 kernel (A/B switch; same bits)
-      const bool v2 = !sdmi_opt(OPT_conv_win_v1) && p.Cin % 64 == 0 && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
-                      ((long long)(128 + 16) + 2 * p.W) * p.lda * 2 + 2 * p.Cin < (1ll << 31);
-      if (vi == 1) {
+      const bool v2 = conv_win2_ok(p, bm);
+      if (vi == VI_WIN256) {
+        launch_win2<256, 128>(grid, wbytes256, st, p);
+      } else if (vi == 1) {
         static unsigned long long attr_done = 0;
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1742,7 +1767,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 64, true>), grid, dim3(256), wbytes64, st, p);
         else hipLaunchKernelGGL((conv_win_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);
       }
-      sdmi_note_kernel("%s<128, %d, %s>%s", v2 ? "conv_win2_kernel" : "conv_win_kernel", bn, p.colstats ? "true" : "false",
+      sdmi_note_kernel("%s<%d, %d, %s>%s", v2 ? "conv_win2_kernel" : "conv_win_kernel", bm, bn, p.colstats ? "true" : "false",
                        (p.splits > 1 && !p.ticket) ? (split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
       int rcw = sdmi_check_launch("conv3x3 (shared window)");
       if (rcw || p.splits < 2 || p.ticket) return rcw;
@@ -1789,6 +1814,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     case 4: launch_variant<64, 64, 2, 2, CONV, 3>(grid, st, p); break;
     default:
       if constexpr (!CONV) {  // GEMM-only variants
+        if (vi == VI_WIN256) { sdmi_set_error("gemm: tile variant %d is conv-only", vi); return SDMI_EINVAL; }
         if (vi == 5) launch_variant<64, 64, 2, 2, false, 5>(grid, st, p);
         else if (vi == 6) launch_variant<128, 64, 2, 2, false, 3>(grid, st, p);
         else launch_variant<64, 128, 2, 2, false, 4>(grid, st, p);

@@ -176,6 +176,43 @@ def test_conv_win2_bit_identical_to_conv_win_and_generic(n, hh, ww, cin, cout, s
     assert e[1] < 6e-4 * _tol(), e
 
 
+@pytest.mark.parametrize("n,hh,ww,cin,cout,stats", [
+    (1, 64, 64, 128, 128, True),      # M % 256 = 0, statistics from the epilogue (four 32-row parts per wave)
+    (2, 36, 20, 128, 256, False),     # M = 1440: the last tile is partial and spans the image boundary
+])
+def test_conv_win2_256_row_tiles_same_bits(n, hh, ww, cin, cout, stats):
+    """conv_win2_kernel<256, 128> (opt-in, conv_win_256 = 1: measured slower, kept as an experiment) against the 128-row
+    tiles: same bits, same column statistics."""
+    lib = L.load()
+    rs = np.random.RandomState(hh + cout)
+    H = E.act_dtype()
+    x = E.Act(T(rs.randn(n, hh * ww, cin).astype(np.float32)).to(DEV).to(H), n, hh, ww, cin)
+    W = torch.nn.Parameter(T((rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)).to(DEV))
+    b = T(rs.randn(cout).astype(np.float32)).to(DEV)
+    res = E.Act(T(rs.randn(n, hh * ww, cout).astype(np.float32)).to(DEV).to(H), n, hh, ww, cout)
+    saved = E.USE_COLSTATS
+    outs, kern, cstat = {}, {}, {}
+    try:
+        E.USE_COLSTATS = stats
+        lib.sdmi_tune_override(1, 1)
+        for v in (0, 1):
+            lib.sdmi_set_option(b"conv_win_256", v)
+            if v:
+                lib.sdmi_tune_override(-1, 1)
+            y = E.conv3x3(x, W, b, residual=res)
+            torch.cuda.synchronize()
+            outs[v], kern[v], cstat[v] = y.buf.clone(), lib.sdmi_last_kernel().decode(), y.stats.get(0)
+    finally:
+        E.USE_COLSTATS = saved
+        lib.sdmi_set_option(b"conv_win_256", 0)
+        lib.sdmi_tune_override(-1, -1)
+    print(kern)
+    assert kern[0].startswith("conv_win2_kernel<128, 128") and kern[1].startswith("conv_win2_kernel<256, 128")
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    if stats:
+        assert cstat[0] is not None and cstat[1] is not None and torch.equal(cstat[0][0], cstat[1][0])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # GEMM staging through buffer descriptors (round 3) against the pointer-per-lane loader: same bits on every epilogue
 @pytest.mark.parametrize("m,n,k,kind", [
