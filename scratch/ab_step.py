@@ -12,13 +12,14 @@ dev = torch.device("cuda", 0)
 lib = _lib.load(); torch.set_grad_enabled(False)
 unet, vae = bench.build_models(dev)
 unet = unet.to(dev)
-L = 96
-x = torch.randn(1, 9, L, L, device=dev).repeat(2, 1, 1, 1)
-t = torch.full((2,), 501, dtype=torch.long, device=dev)
-uncond, cond = torch.randn(1, 77, 1024, device=dev), torch.randn(1, 77, 1024, device=dev)
+L = int(os.environ.get("AB_L", "96"))      # latent size (96 = 768 px); AB_B = images per GPU
+B = int(os.environ.get("AB_B", "1"))
+x = torch.randn(B, 9, L, L, device=dev).repeat(2, 1, 1, 1)
+t = torch.full((2 * B,), 501, dtype=torch.long, device=dev)
+uncond, cond = torch.randn(B, 77, 1024, device=dev), torch.randn(B, 77, 1024, device=dev)
 te = unet.precompute_time_embedding(t)
 
-OPTION_DEFAULTS = {"attn_variant": 0, "gemm_small_m_tile": 1, "conv_nmajor_by_rows": 0, "splitk_target": 0, "splitk_max_tiles": 0, "attn_x2_min_nq": 0, "splitk_min_kt_conv": 0, "splitk_min_kt_gemm": 0, "bm128_min": 0, "gemm_t2_min_blocks": 0, "split_colstats_off": 0, "gemm_persist": 0, "conv_win_v1": 0, "gemm_buf_off": 0}
+OPTION_DEFAULTS = {"conv_plan_r2": 0, "attn_pp": 0, "conv_win_256": 0, "attn_variant": 0, "gemm_small_m_tile": 1, "conv_nmajor_by_rows": 0, "splitk_target": 0, "splitk_max_tiles": 0, "attn_x2_min_nq": 0, "splitk_min_kt_conv": 0, "splitk_min_kt_gemm": 0, "bm128_min": 0, "gemm_t2_min_blocks": 0, "split_colstats_off": 0, "gemm_persist": 0, "conv_win_v1": 0, "gemm_buf_off": 0}
 def apply(cfg):
     for k, v in OPTION_DEFAULTS.items():        # options are process-wide: every configuration starts from the defaults
         lib.sdmi_set_option(k.encode(), v)

@@ -1440,6 +1440,14 @@ static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags, boo
   const int min_kt = opt_kt > 0 ? opt_kt : (conv ? 16 : 24);
   if (s > nk / min_kt) s = nk / min_kt;
   if (s > 16) s = 16;
+  if (conv && !sdmi_opt(OPT_conv_plan_r2)) {
+    // round 3, batch-1 sweep with the round-3 kernels (profiles/r03_sweep_conv_b1.txt):
+    // - a 48x48 conv with 320 input channels (45 K-tiles) runs 25 % faster unsplit on 128 x 64 tiles (180 of them) than as
+    //   two splits of 128 x 128 tiles + a reduce kernel;
+    // - the 12x12 convs with 2560 input channels: 12 splits instead of 16 (-14 %: a third less partial traffic)
+    if (nk < 48 && rows_per_sample >= 2048) return 1;
+    if (rows_per_sample <= 256 && s > 12) s = 12;
+  }
   return s < 2 ? 1 : (int)s;
 }
 
@@ -1621,6 +1629,9 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   if (conv && bn128 && p.N % 128 == 0 && sdmi_opt(OPT_conv_win_256) > 0 && conv_window_shape(p, batch) && conv_win2_ok(p, 256)) return VI_WIN256;
   if (bm128 && bn128) return 1;
   if (bm128) return 2;
+  // (round 3) unsplit short-K convs whose 128 x 128 grid is too small: 128 x 64 tiles once there are 160 of them
+  if (conv && bn128 && p.splits == 1 && !sdmi_opt(OPT_conv_plan_r2) && p.M > 64 &&
+      (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * batch >= 160) return 2;
   if (bn128) return 3;
   return 4;
 }
