@@ -1437,7 +1437,9 @@ static int splitk_factor(int rows_per_sample, int n, int nk, uint32_t flags, boo
   // halves as concurrent batch-1 passes (scratch/ab_step.py, same-process A/B of the captured step): 512 blocks per
   // sample instead of 384 and splitting up to 256 tiles instead of 128 -1.3 %, GEMM splits from K = 3072 -0.5 %.
   const int opt_kt = sdmi_opt(conv ? OPT_splitk_min_kt_conv : OPT_splitk_min_kt_gemm);
-  const int min_kt = opt_kt > 0 ? opt_kt : (conv ? 16 : 24);
+  // (round 3, with conv_win2_kernel: at least 24 K-tiles per conv split instead of 16 - fewer, longer splits: captured step
+  // 8.043 -> 7.965 and 8.005 -> 7.979 ms in two interleaved runs, 32 equal, 48 +4 %; conv_plan_r2 = 1 restores 16)
+  const int min_kt = opt_kt > 0 ? opt_kt : (conv ? (sdmi_opt(OPT_conv_plan_r2) ? 16 : 24) : 24);
   if (s > nk / min_kt) s = nk / min_kt;
   if (s > 16) s = 16;
   if (conv && !sdmi_opt(OPT_conv_plan_r2)) {
@@ -1619,9 +1621,12 @@ static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   // 128-row tiles (and with them the shared-window conv kernel) once they give half the CUs a block: the sampler runs
   // the two CFG halves as concurrent batch-1 passes, so the other half of the chip is not idle (256 -> 128: +3.3 %
   // images/s at 768x768; SDMI_BM128_MIN overrides)
-  static const int bm128_min = [] { const char* e = getenv("SDMI_BM128_MIN"); return e ? atoi(e) : 128; }();
+  // (round 3, with the round-3 kernels and split rules: 192 instead of 128 - captured step 7.979 -> 7.927 and 8.135 -> 8.086 ms
+  // in two interleaved runs, 160 ... 224 equal, 256 +1.5 %; conv_plan_r2 = 1 restores 128)
+  static const int bm128_env = [] { const char* e = getenv("SDMI_BM128_MIN"); return e ? atoi(e) : 0; }();
   const int opt_bm = sdmi_opt(OPT_bm128_min);
-  const bool bm128 = p.M > 64 && tiles128 >= (opt_bm > 0 ? opt_bm : bm128_min);
+  const int bm128_min = opt_bm > 0 ? opt_bm : (bm128_env > 0 ? bm128_env : (sdmi_opt(OPT_conv_plan_r2) ? 128 : 192));
+  const bool bm128 = p.M > 64 && tiles128 >= bm128_min;
   // 256 x 128 window tiles (4 waves x 128 x 64: 1.5 fragment reads per 4 MFMAs instead of 2): opt-in (conv_win_256 = 1).
   // The same loop at one block per CU and one wave per SIMD is 13-38 % SLOWER on the VAE's levels and 17-24 % at batch 4
   // (profiles/r03_conv_win256_ab.txt; same bits): what a larger wave tile saves in LDS reads it loses to the waits a lone
