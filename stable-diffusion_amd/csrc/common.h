@@ -54,6 +54,7 @@ void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the 
   X(attn_pipe_off, 0, "1: long self-attention with the lockstep block of round 2 instead of the software-pipelined one, A/B switch")             \
   X(attn_pp, 0, "1: long self-attention on the two-group 8-wave kernel attn64pp_kernel (not faster: DESIGN.md, round 3)")                           \
   X(conv_win_256, 0, "1: 256 x 128 shared-window conv tiles wherever the kernel can run the problem (measured slower: an experiment)")              \
+  X(gemm_astat, 0, "1: A-stationary GEMM kernel (igemm_astat_kernel) for K <= 384 wherever it can run the problem (measured slower)")           \
   X(conv_plan_r2, 0, "1: split-K / tile rules of the convs as in round 2 (A/B switch for the round-3 rule changes)")                              \
   X(conv_win_v1, 0, "1: shared-window convs on the round-2 kernel (global_load_lds + per-lane pointers), A/B switch")
 enum SdmiOpt {

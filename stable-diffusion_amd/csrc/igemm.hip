@@ -1037,6 +1037,158 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 #undef PGEMM_MFMA_ALL
 }
 
+// ------------------------------------------------------------------------------------------ A-stationary GEMM (round 3)
+// The K = 320 GEMMs of the 96x96 transformer blocks (to_q|k|v: N = 960, GEGLU proj: N = 2560; M = 9216 per CFG half) are
+// bound by the L2 -> LDS path: a 128 x 128 tile stages (128 + 128) x 320 x 2 B for 5 K-tiles of work, 236 MB per GEGLU launch
+// at the ~7.7 TB/s every LDS-staged kernel here tops out at.  Half of that is the activation panel,
+// staged again by each of the row tile's 20 column tiles.  Here a block keeps its 128 x K activation panel RESIDENT in the
+// LDS (80 KB at K = 320) and walks a run of column tiles with it; only the weight tiles stream (a three-slot ring that runs
+// on across column tiles, so the next tile's first K-tiles land under the current tile's epilogue).  Grid = row tiles x
+// nsplit column runs, about one block per CU (130 KB of LDS); ids are run-major, so the blocks an XCD holds share their
+// weight columns.  Same K order, same arithmetic, same epilogue (igemm_finish) as igemm_kernel: same bits (tested).
+// Needs K % 64 = 0, K <= 384, the 16-byte epilogue, batch 1, no split-K.
+template <int BN, bool GEGLU>
+__global__ __launch_bounds__(256, 1) void igemm_astat_kernel(const IgemmParams p, int nsplit) {
+  constexpr int BM = 128, WN = 2, NSTAGE = 3, NTH = 256;
+  constexpr int TM = 64, TN = BN / WN, MT = TM / 16, NT = TN / 16, PA = BM / 32, PB = BN / 32;
+  constexpr int ASLAB = BM * BK, BSLOT = BN * BK;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];  // [nk][BM x BK] panel | [NSTAGE][BN x BK] weight ring | LayerNorm side
+  const int nk = p.nk;
+  u16* const bring = smem + nk * ASLAB;
+  float* const lnside = (float*)(bring + NSTAGE * BSLOT);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv / WN, wc = wv % WN, l15 = lane & 15, lq = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * nsplit);
+  const int part = bid / tiles_m, brow = (bid % tiles_m) * BM;
+  const int c0 = (int)((long long)part * tiles_n / nsplit), c1 = (int)((long long)(part + 1) * tiles_n / nsplit);
+  const int r0 = t >> 3;
+  const int lchunk = (t & 7) ^ ((r0 >> 1) & 7);
+  const int wave_row0 = __builtin_amdgcn_readfirstlane(wv) * 8;
+  const unsigned lds0 = lds_addr_of(smem);
+
+  // descriptors end with the last row of the operand: rows of the tile past M / columns past N arrive as zeros
+  const int rows_here = min(BM, p.M - brow);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + (long long)brow * p.lda), 0, (unsigned)((rows_here - 1) * p.lda + p.K) * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)(((long long)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+  unsigned a_voff[PA], b_voff[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) a_voff[i] = (unsigned)(((r0 + 32 * i) * p.lda + lchunk * 8) * 2);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) b_voff[i] = (unsigned)(((r0 + 32 * i) * p.ldw + lchunk * 8) * 2);
+
+  // the whole activation panel, then the first weight tiles
+  for (int kt = 0; kt < nk; ++kt)
+#pragma unroll
+    for (int i = 0; i < PA; ++i) dma_buf16(rsrcA, a_voff[i], __builtin_amdgcn_readfirstlane(kt * (BK * 2)), lds0 + (kt * ASLAB + (wave_row0 + 32 * i) * BK) * 2);
+  int s_ct = c0, s_k = 0;  // staging cursor: runs NSTAGE K-tiles ahead of the multiplication, across column tiles
+#define AGEMM_STAGE_NEXT(SLOT)                                                                                     \
+  {                                                                                                                \
+    const bool live_ = s_ct < c1;                                                                                  \
+    const int soff_ = __builtin_amdgcn_readfirstlane(live_ ? (s_ct * BN * p.ldw + s_k * BK) * 2 : 0);              \
+    _Pragma("unroll") for (int i = 0; i < PB; ++i)                                                                 \
+      dma_buf16(live_ ? rsrcB : rsrcZ, b_voff[i], soff_, lds0 + (nk * ASLAB + (SLOT) * BSLOT + (wave_row0 + 32 * i) * BK) * 2); \
+    if (++s_k == nk) { s_k = 0; ++s_ct; }                                                                          \
+  }
+#define AGEMM_WAIT_STAGE(GROUPS)                                                   \
+  {                                                                                \
+    constexpr int INFLIGHT = (GROUPS) * PB;                                        \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");     \
+    __builtin_amdgcn_s_barrier();                                                  \
+  }
+#define AGEMM_READ_FRAGS(AF, WF, KT, SLOT, KK)                                                                      \
+  {                                                                                                                 \
+    const u16* cA = smem + (KT) * ASLAB;                                                                            \
+    const u16* cB = bring + (SLOT) * BSLOT;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) AF[i] = *(const hx8*)&cA[lds_off(wr * TM + i * 16 + l15, lq + 4 * (KK))]; \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) WF[j] = *(const hx8*)&cB[lds_off(wc * TN + j * 16 + l15, lq + 4 * (KK))]; \
+  }
+#define AGEMM_MFMA_ALL(AF, WF)                                                                 \
+  {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                             \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(WF[j], AF[i], acc[i][j], 0, 0, 0); \
+  }
+#pragma unroll
+  for (int sidx = 0; sidx < NSTAGE; ++sidx) AGEMM_STAGE_NEXT(sidx);
+
+  // LayerNorm fold: (mean, rstd) of the tile's rows, once per block (as igemm_kernel: fixed order, finished in double)
+  if (p.ln_stats) {
+    constexpr int TPR = NTH / BM;  // 2 threads per row
+    const int lrow = t / TPR, sub = t % TPR;
+    const int row = min(brow + lrow, p.M - 1);
+    const float2* sp = (const float2*)p.ln_stats + (long long)row * p.ln_parts;
+    constexpr int NA = 4 / TPR;
+    float a0[NA], a1[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a0[j] = a1[j] = 0.f;
+    constexpr int ROUNDS = 6;
+    for (int pp = 0; pp < p.ln_parts; pp += 4 * ROUNDS) {
+      float2 v[ROUNDS][NA];
+#pragma unroll
+      for (int rr = 0; rr < ROUNDS; ++rr)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int q = pp + 4 * rr + sub + j * TPR;
+          v[rr][j] = q < p.ln_parts ? sp[q] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+      for (int rr = 0; rr < ROUNDS; ++rr)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) { a0[j] += v[rr][j].x; a1[j] += v[rr][j].y; }
+    }
+    const float b0 = a0[0] + __shfl_xor(a0[0], 1), b1 = a1[0] + __shfl_xor(a1[0], 1);
+    const float d0 = a0[1] + __shfl_xor(a0[1], 1), d1 = a1[1] + __shfl_xor(a1[1], 1);
+    const float s0 = b0 + d0, s1 = b1 + d1;
+    if (sub == 0) {
+      const double inv = 1.0 / (double)p.K;
+      const double mean = (double)s0 * inv;
+      const double var = fmax((double)s1 * inv - mean * mean, 0.0);
+      ((float2*)lnside)[lrow] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.ln_eps)));
+    }
+  }
+
+  int slot = 0;
+  for (int ct = c0; ct < c1; ++ct) {
+    const int bcol = ct * BN;
+    if (ct != c0) {
+      // the previous tile's stores are out and its reads of the side region are done before anything of this tile is
+      // counted or written (loads and stores do not retire in one order: the counted waits below must not see stores)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    hx8 af0[MT], wf0[NT], af1[MT], wf1[NT];
+    EpiRegs<TM, TN, GEGLU> er;
+    epi_prefetch<TM, TN, GEGLU>(p, er, 0, brow + wr * TM, bcol + wc * TN, lane);
+    if (p.ln_stats)
+      for (int c = t; c < BN; c += NTH) lnside[2 * BM + c] = bcol + c < p.N ? p.ln_u[bcol + c] : 0.f;
+    AGEMM_WAIT_STAGE(NSTAGE - 1);
+    AGEMM_READ_FRAGS(af0, wf0, 0, slot, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+      const int nkt = kt + 1 == nk ? 0 : kt + 1;
+      AGEMM_READ_FRAGS(af1, wf1, kt, slot, 1);
+      AGEMM_MFMA_ALL(af0, wf0);
+      AGEMM_WAIT_STAGE(NSTAGE - 2);
+      AGEMM_STAGE_NEXT(slot);
+      AGEMM_READ_FRAGS(af0, wf0, nkt, nslot, 0);
+      AGEMM_MFMA_ALL(af1, wf1);
+      slot = nslot;
+    }
+    igemm_finish<TM, TN, GEGLU, true, true>(p, acc, er, true, smem, 0, brow + wr * TM, bcol + wc * TN, (lds_cfp)lnside, BM, wr * TM, wc * TN,
+                                            (brow + wr * TM) / 32, (bcol + wc * TN) / 32);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef AGEMM_STAGE_NEXT
+#undef AGEMM_WAIT_STAGE
+#undef AGEMM_READ_FRAGS
+#undef AGEMM_MFMA_ALL
+}
+
 // ------------------------------------------------------------------------------------------ shared-window 3x3 conv
 // Stride-1, pad-1 convolutions.  The generic kernel stages a fresh 128 x 64 activation tile for each of the 9 taps; the
 // three taps of one kernel row (kx = 0, 1, 2) read the SAME pixels shifted by one, so here ONE window of BM + 2 pixel
@@ -1550,6 +1702,19 @@ static void launch_variant(dim3 grid, hipStream_t st, const IgemmParams& p) {
   launch_variant2<BM, BN, WM, WN, CONV, NSTAGE, false>(grid, st, p);
 }
 
+// A-stationary launch (igemm_astat_kernel): tiles_m x nsplit blocks, dynamic LDS = panel + ring + LayerNorm side region
+template <int BN, bool GEGLU>
+static void launch_astat2(int blocks, int nsplit, int bytes, hipStream_t st, const IgemmParams& p) {
+  auto kfn = igemm_astat_kernel<BN, GEGLU>;
+  static unsigned long long attr_done = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_done >> (dev & 63)) & 1ull)) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    attr_done |= 1ull << (dev & 63);
+  }
+  hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), bytes, st, p, nsplit);
+}
 // persistent launch (igemm_persist_kernel): `slots` blocks walk the nb tiles
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool GEGLU>
 static void launch_persist2(int slots, int batch, hipStream_t st, const IgemmParams& p) {
@@ -1794,6 +1959,39 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
       if (split_colstats) hipLaunchKernelGGL(igemm_splitk_reduce_stats_kernel, dim3((unsigned)((p.M / 32) * ((p.N + 31) / 32))), dim3(256), 0, st, p, split_colstats);
       else hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
       return sdmi_check_launch("split-K reduce");
+    }
+  }
+  // A-stationary blocks for short-K GEMMs with many column tiles per row tile: opt-in (gemm_astat = 1).  Same bits, half the
+  // staged bytes, and 14-35 % SLOWER on every K = 320 GEMM tried (profiles/r03_gemm_astat_ab.txt: 9216 x 2560 x 320 GEGLU
+  // 40.1 against 29.5 us): at one block per CU and one wave per SIMD a tile's K loop (five barrier-separated K-tiles) and
+  // its epilogue run one after the other, ~5.7 us per tile, where two or three co-resident tile-per-block blocks overlap
+  // them - these GEMMs are bound by that dependent chain per tile, not by the bytes through the L2 -> LDS path.
+  if constexpr (!CONV) {
+    const int aopt = sdmi_opt(OPT_gemm_astat);
+    const bool geglu = (p.flags & SDMI_F_GEGLU) != 0;
+    if (aopt > 0 && (vi == 1 || vi == 2) && batch == 1 && p.splits == 1 && p.fast_epi && p.K % 64 == 0 && p.nk <= 6 && p.N % bn == 0 &&
+        (!geglu || vi == 1) && (long long)p.N * p.ldw * 2 < (1ll << 31) && (long long)128 * p.lda * 2 < (1ll << 31)) {
+      static int cus[64] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (!cus[dev & 63]) {
+        int n = 0;
+        cus[dev & 63] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+      }
+      const int tiles_m = (p.M + 127) / 128, tiles_n = p.N / bn;
+      int nsplit = cus[dev & 63] / tiles_m;
+      nsplit = nsplit < 1 ? 1 : (nsplit > tiles_n ? tiles_n : nsplit);
+      {
+        const int bytes = (p.nk * 128 * BK + 3 * bn * BK) * 2 + (2 * 128 + bn) * 4;
+        if (vi == 1) {
+          if (geglu) launch_astat2<128, true>(tiles_m * nsplit, nsplit, bytes, st, p);
+          else launch_astat2<128, false>(tiles_m * nsplit, nsplit, bytes, st, p);
+        } else {
+          launch_astat2<64, false>(tiles_m * nsplit, nsplit, bytes, st, p);
+        }
+        sdmi_note_kernel("igemm_astat_kernel<%d, %s>", bn, geglu ? "true" : "false");
+        return sdmi_check_launch("gemm (A-stationary)");
+      }
     }
   }
   // Persistent blocks, the next tile's first K-tiles fetched under the current tile's tail and epilogue: an opt-in

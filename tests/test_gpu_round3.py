@@ -264,6 +264,62 @@ def test_gemm_buffer_staging_bit_identical(m, n, k, kind):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# A-stationary GEMM kernel (round 3, opt-in - measured slower: the activation panel of a row tile stays in the LDS for a run of
+# column tiles) against igemm_kernel: same bits on every epilogue it takes, on shapes that end inside a row tile, with one and with several runs
+@pytest.mark.parametrize("m,n,k,kind", [
+    (9216, 960, 320, "ln"),          # to_q|k|v of the 96x96 level: LayerNorm folded in, 128 x 64 tiles, three runs of five
+    (9216, 2560, 320, "geglu"),      # GEGLU proj: 128 x 128 tiles
+    (9216, 2560, 320, "geglu_ln"),   # ... with the LayerNorm fold, as the UNet runs it
+    (9216, 320, 320, "res"),         # residual + bias + row statistics (forced: one run of five tiles per block)
+    (1000, 512, 192, "plain"),       # M % 128 = 104: rows past M arrive as zeros
+    (18432, 960, 384, "plain"),      # six K-tiles, 144 row tiles: one run per row tile
+])
+def test_gemm_a_stationary_bit_identical(m, n, k, kind):
+    lib = L.load()
+    rs = np.random.RandomState(m + n + k)
+    H = E.act_dtype()
+    a = E.Act(T(rs.randn(1, m, k).astype(np.float32)).to(DEV).to(H), 1, 1, m, k)
+    w = T((rs.randn(n, k) / np.sqrt(k)).astype(np.float32)).to(DEV).to(H).contiguous()
+    b = T(rs.randn(n).astype(np.float32)).to(DEV)
+    geglu = kind.startswith("geglu")
+    nout = n // 2 if geglu else n
+    res = E.Act(T(rs.randn(1, m, nout).astype(np.float32)).to(DEV).to(H), 1, 1, m, nout) if kind == "res" else None
+    if kind.endswith("ln"):
+        w0 = T((rs.randn(k, k) / np.sqrt(k)).astype(np.float32)).to(DEV).to(H).contiguous()
+        a = E.gemm(a, w0, k, rowstats=True)
+        lnm = torch.nn.LayerNorm(k).to(DEV)
+        with torch.no_grad():
+            lnm.weight.copy_(T(rs.rand(k).astype(np.float32) + 0.5)); lnm.bias.copy_(T(rs.randn(k).astype(np.float32) * 0.1))
+        W1 = torch.nn.Parameter(w.float())
+    outs, kern = {}, {}
+    try:
+        if m < 2048:
+            lib.sdmi_tune_override(2, 1)     # (a grid this small takes 64-row tiles by itself: 128 x 64 forced)
+        for v in (0, 1):
+            lib.sdmi_set_option(b"gemm_astat", v)
+            if kind.endswith("ln"):
+                y = E.gemm_ln(a, lnm, (W1,), bias=torch.nn.Parameter(b), geglu=geglu)
+            else:
+                y = E.gemm(a, w, n, bias=b, residual=res, geglu=geglu, rowstats=(kind == "res"))
+            torch.cuda.synchronize()
+            outs[v], kern[v] = y.buf.clone(), lib.sdmi_last_kernel().decode()
+            if kind == "res":
+                outs[("rs", v)] = y.rstats[0].clone() if y.rstats is not None else None
+    finally:
+        lib.sdmi_set_option(b"gemm_astat", 0)
+        lib.sdmi_tune_override(-1, -1)
+    print(kern)
+    assert kern[0].startswith("igemm_kernel") and kern[1].startswith("igemm_astat_kernel")
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "A-stationary and tile-per-block kernels differ"
+    if kind == "res" and outs[("rs", 0)] is not None:
+        assert torch.equal(outs[("rs", 0)], outs[("rs", 1)])
+    if kind in ("plain", "res"):
+        ref = a.buf[0].float() @ w.float().t() + b + (res.buf[0].float() if res is not None else 0.0)
+        e = rel_err(outs[1][0].float().cpu().numpy(), ref.cpu().numpy())
+        assert e[1] < 6e-4 * _tol(), e
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # fp16 dynamic range (round-2 review): the library saturates on store, so a checkpoint whose VAE activations pass 65504 is
 # clipped.  The clip is not silent to a caller who asks: engine.RANGE_AUDIT counts the clipped elements per layer.
 def test_range_audit_reports_clipped_vae_layers():
