@@ -484,7 +484,10 @@ __device__ __forceinline__ void attn2_dma16(const void* src, unsigned lds_byte_a
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
 }
 
-template <bool PIPE>
+// BUFS (round 3): K / V staging through buffer descriptors (32-bit offsets; host: nkv * ld * 2 < 2^31) - no 64-bit address
+// arithmetic per DMA instruction, and the partial last tile needs no clamped second path: rows past nkv arrive as zeros
+// (their scores are masked either way: same bits)
+template <bool PIPE, bool BUFS>
 __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnParams p) {
   // tile images [stream][buffer][K | V]; afterwards the second stream's O passes through its images to the first stream
   __shared__ __attribute__((aligned(16))) u16 smem[2 * 2 * 2 * 4096];
@@ -570,9 +573,21 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(const AttnParams p) {
       attn2_dma16(V + (long long)key * p.ldv + (spos ^ (((row >> 1) & 1) << 2)) * 8, dst + 8192 + j * 1024);
     }
   };
+  const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, BUFS ? (unsigned)((p.nkv - 1) * p.ldk * 2 + 128) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, BUFS ? (unsigned)((p.nkv - 1) * p.ldv * 2 + 128) : 0u, 0x00020000);
   auto stage = [&](int tile, int buf) {
-    if ((tile + 1) * 64 <= p.nkv) stage_full(tile, buf);
-    else stage_tail(tile, buf);
+    if constexpr (BUFS) {
+      const unsigned dst = lds0 + buf * 16384;
+      const unsigned sk_ = tile * (unsigned)stepk, sv_ = tile * (unsigned)stepv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dma_buf16(rsrcK, offk[j] + sk_, 0, dst + j * 1024);
+        dma_buf16(rsrcV, offv[j] + sv_, 0, dst + 8192 + j * 1024);
+      }
+    } else {
+      if ((tile + 1) * 64 <= p.nkv) stage_full(tile, buf);
+      else stage_tail(tile, buf);
+    }
   };
 #define ATTN2_END_TILE()                                  \
   {                                                       \
@@ -986,8 +1001,9 @@ static int attention_launch(const void* q, int ldq, int64_t sq, const void* k, i
       return sdmi_check_launch("attention (two wave groups)");
     }
     // attn_pipe_off = 1: the lockstep block of round 2 (A/B switch; same bits)
-    if (sdmi_opt(OPT_attn_pipe_off)) hipLaunchKernelGGL(attn64x2_kernel<false>, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn64x2_kernel<true>, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
+    if (sdmi_opt(OPT_attn_pipe_off)) hipLaunchKernelGGL((attn64x2_kernel<false, false>), dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
+    else if (pp_ok && !sdmi_opt(OPT_attn_buf_off)) hipLaunchKernelGGL((attn64x2_kernel<true, true>), dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn64x2_kernel<true, false>), dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
     sdmi_note_kernel("attn64x2_kernel");
     return sdmi_check_launch("attention (64 rows per wave)");
   }

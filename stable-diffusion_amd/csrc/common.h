@@ -52,6 +52,7 @@ void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the 
   X(attn_variant, 0, "attention kernel variant (0 = default)")                                                                                   \
   X(gemm_buf_off, 0, "1: GEMMs stage with the round-2 pointer-per-lane loader instead of buffer descriptors, A/B switch")                         \
   X(attn_pipe_off, 0, "1: long self-attention with the lockstep block of round 2 instead of the software-pipelined one, A/B switch")             \
+  X(attn_buf_off, 0, "1: attn64x2_kernel stages K / V with per-lane pointers (round 2) instead of buffer descriptors, A/B switch")                \
   X(attn_pp, 0, "1: long self-attention on the two-group 8-wave kernel attn64pp_kernel (not faster: DESIGN.md, round 3)")                           \
   X(conv_win_256, 0, "1: 256 x 128 shared-window conv tiles wherever the kernel can run the problem (measured slower: an experiment)")              \
   X(gemm_astat, 0, "1: A-stationary GEMM kernel (igemm_astat_kernel) for K <= 384 wherever it can run the problem (measured slower)")           \
