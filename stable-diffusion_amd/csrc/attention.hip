@@ -24,6 +24,11 @@ struct AttnParams {
 
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 1) << 2)) << 3); }
+// eight packed words of P (32 keys of one chain) and their row-sum helpers (see A3_E2)
+union A3P { hx8 v; hx2 h[4]; };
+__device__ __forceinline__ hx2 a3_ones() { return hx2{(h16)1.0f, (h16)1.0f}; }
+#define A3_SUM4(P) (((P).h[0] + (P).h[1]) + ((P).h[2] + (P).h[3]))
+#define A3_LADD(L, TA, TB) L = DOT2H((TA) + (TB), a3_ones(), L)
 
 // One KV tile for one wave: S^T = K Q^T, online softmax with the query on the lane, O^T += V^T P^T.
 template <bool TAIL>
@@ -283,18 +288,19 @@ __device__ __forceinline__ void attn2_block(const u16* sK, const u16* sV, int kb
     }
   }
   // exp -> fp16 P -> PV in two 16-key halves: the second half's exps issue behind the first half's MFMAs
+  hx2 lpart[2];
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
     hx8 pb[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // (the operations of A3_E2, in its order: the pipelined block gives the same bits)
-        const float e0 = __builtin_amdgcn_exp2f(s[qb][8 * s2 + 2 * j]), e1 = __builtin_amdgcn_exp2f(s[qb][8 * s2 + 2 * j + 1]);
-        pb[qb][2 * j] = (h16)e0;
-        pb[qb][2 * j + 1] = (h16)e1;
-        lrun[qb] += e0 + e1;
-      }
+      for (int j = 0; j < 8; ++j) pb[qb][j] = (h16)__builtin_amdgcn_exp2f(s[qb][8 * s2 + j]);
+      // row sums of the rounded P (the operations of attn3_block, in its order: same bits)
+      A3P u;
+      u.v = pb[qb];
+      if (s2 == 0) lpart[qb] = A3_SUM4(u);
+      else A3_LADD(lrun[qb], lpart[qb], A3_SUM4(u));
     }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
@@ -329,20 +335,19 @@ __device__ __forceinline__ void attn2_block(const u16* sK, const u16* sV, int kb
 // the results are bit-identical (tested).  The order is pinned with sched_barrier fences: left alone the scheduler clusters
 // the MFMAs again.
 #define A3_FENCE() __builtin_amdgcn_sched_barrier(0)
-union A3P { hx8 v; hx2 h[4]; };
-// two scores -> one packed word of P, and their part of the row sum.  The sum takes the unrounded exponentials through
-// v_add_f32: v_dot2c_f32_f16 on the rounded pair (round 2) is one instruction less, but it does not run beside another
-// wave's MFMAs (scratch/mb/coexec2.hip, profiles/r03_coexec2.txt: 32 of them next to 8 MFMAs take 245 ns, against
-// 138 | 76 ns alone, as do v_dot2_f32_f16, v_pk_mul_f32, v_pk_add_f32; v_add_f32 overlaps 64 %): -1.5 ... -4 % on the
-// long self-attention shapes.
-#define A3_E2(S, K, W, L)                                          \
+// two scores -> one packed word of P.  Row sums (round 3, third form): the eight packed words of a 32-key block are added
+// as fp16 pairs in a tree (v_pk_add_f16: seven instructions, each sum <= 8 x 256) and the two halves of the result enter
+// the fp32 row sum through ONE v_dot2c - eight instructions per block and chain.  Round 2 took a v_dot2c per word (eight,
+// but the dot instructions do not run beside another wave's MFMAs: scratch/mb/coexec2.hip, profiles/r03_coexec2.txt - 32
+// of them next to 8 MFMAs take 245 ns against 138 | 76 alone, as do v_dot2_f32_f16, v_pk_mul_f32, v_pk_add_f32, while
+// v_pk_add_f16 overlaps like any plain vector instruction); the first round-3 form took v_add_f32 on the unrounded
+// exponentials (sixteen, -1.5 ... -4 %).  The sum is that of the ROUNDED P, what the P.V product sees.
+#define A3_E2(S, K, W)                                             \
   {                                                                \
-    const float e0_ = __builtin_amdgcn_exp2f(S[2 * (K)]), e1_ = __builtin_amdgcn_exp2f(S[2 * (K) + 1]); \
     hx2 w_;                                                        \
-    w_[0] = (h16)e0_;                                              \
-    w_[1] = (h16)e1_;                                              \
+    w_[0] = (h16)__builtin_amdgcn_exp2f(S[2 * (K)]);               \
+    w_[1] = (h16)__builtin_amdgcn_exp2f(S[2 * (K) + 1]);           \
     W = w_;                                                        \
-    L += e0_ + e1_;                                                \
   }
 // row maximum of one chain's block and, rarely, the move of its running maximum (as in attn2_block, per chain)
 template <bool FIRST>
@@ -397,28 +402,31 @@ __device__ __forceinline__ void attn3_block(const u16* sK, const u16* sV, int kb
   f32x16 s0;
   A3P p1a, p1b, p0a, p0b;
   // ---- Q0 | E1a
-  if constexpr (!FIRST) A3_E2(s1, 0, p1a.h[0], lrun[1]);
+  if constexpr (!FIRST) A3_E2(s1, 0, p1a.h[0]);
   A3_FENCE();
   asm(MFMA32_MNEMONIC " %0, %1, %2, %3" : "=&v"(s0) : "v"(kf[0]), "v"(qf[0][0]), "v"(negm[0]));
-  if constexpr (!FIRST) A3_E2(s1, 1, p1a.h[1], lrun[1]);
+  if constexpr (!FIRST) A3_E2(s1, 1, p1a.h[1]);
   A3_FENCE();
   s0 = MFMA32(kf[1], qf[0][1], s0, 0, 0, 0);
-  if constexpr (!FIRST) A3_E2(s1, 2, p1a.h[2], lrun[1]);
+  if constexpr (!FIRST) A3_E2(s1, 2, p1a.h[2]);
   A3_FENCE();
   s0 = MFMA32(kf[2], qf[0][2], s0, 0, 0, 0);
-  if constexpr (!FIRST) A3_E2(s1, 3, p1a.h[3], lrun[1]);
+  if constexpr (!FIRST) A3_E2(s1, 3, p1a.h[3]);
   A3_FENCE();
   s0 = MFMA32(kf[3], qf[0][3], s0, 0, 0, 0);
+  hx2 l1a;
+  if constexpr (!FIRST) l1a = A3_SUM4(p1a);
   A3_FENCE();
   // ---- V1a | E1b
   if constexpr (!FIRST) {
     oacc[1][0] = MFMA32(va[0], p1a.v, oacc[1][0], 0, 0, 0);
-    A3_E2(s1, 4, p1b.h[0], lrun[1]);
-    A3_E2(s1, 5, p1b.h[1], lrun[1]);
+    A3_E2(s1, 4, p1b.h[0]);
+    A3_E2(s1, 5, p1b.h[1]);
     A3_FENCE();
     oacc[1][1] = MFMA32(va[1], p1a.v, oacc[1][1], 0, 0, 0);
-    A3_E2(s1, 6, p1b.h[2], lrun[1]);
-    A3_E2(s1, 7, p1b.h[3], lrun[1]);
+    A3_E2(s1, 6, p1b.h[2]);
+    A3_E2(s1, 7, p1b.h[3]);
+    A3_LADD(lrun[1], l1a, A3_SUM4(p1b));
     A3_FENCE();
   }
   // va is free: this block's V fragments for keys 0-15
@@ -430,34 +438,36 @@ __device__ __forceinline__ void attn3_block(const u16* sK, const u16* sV, int kb
   a3_max<FIRST>(s0, oacc[0], negm[0], mrun[0], lrun[0]);
   A3_FENCE();
   s1 = MFMA32(kf[1], qf[1][1], s1, 0, 0, 0);
-  A3_E2(s0, 0, p0a.h[0], lrun[0]);
+  A3_E2(s0, 0, p0a.h[0]);
   A3_FENCE();
   s1 = MFMA32(kf[2], qf[1][2], s1, 0, 0, 0);
-  A3_E2(s0, 1, p0a.h[1], lrun[0]);
+  A3_E2(s0, 1, p0a.h[1]);
   A3_FENCE();
   s1 = MFMA32(kf[3], qf[1][3], s1, 0, 0, 0);
-  A3_E2(s0, 2, p0a.h[2], lrun[0]);
+  A3_E2(s0, 2, p0a.h[2]);
   A3_FENCE();
   // ---- V1b | E0a3, E0b0
   if constexpr (!FIRST) oacc[1][0] = MFMA32(vb[0], p1b.v, oacc[1][0], 0, 0, 0);
-  A3_E2(s0, 3, p0a.h[3], lrun[0]);
+  A3_E2(s0, 3, p0a.h[3]);
   A3_FENCE();
   if constexpr (!FIRST) oacc[1][1] = MFMA32(vb[1], p1b.v, oacc[1][1], 0, 0, 0);
-  A3_E2(s0, 4, p0b.h[0], lrun[0]);
+  A3_E2(s0, 4, p0b.h[0]);
+  const hx2 l0a = A3_SUM4(p0a);
   A3_FENCE();
   // vb is free: this block's V fragments for keys 16-31
   vb[0] = a3_vfrag(sV, kb, 1, 0, hh, dblk, tq, tp);
   vb[1] = a3_vfrag(sV, kb, 1, 1, hh, dblk, tq, tp);
   // ---- V0a | E0b
   oacc[0][0] = MFMA32(va[0], p0a.v, oacc[0][0], 0, 0, 0);
-  A3_E2(s0, 5, p0b.h[1], lrun[0]);
+  A3_E2(s0, 5, p0b.h[1]);
   A3_FENCE();
   oacc[0][1] = MFMA32(va[1], p0a.v, oacc[0][1], 0, 0, 0);
-  A3_E2(s0, 6, p0b.h[2], lrun[0]);
-  A3_E2(s0, 7, p0b.h[3], lrun[0]);
+  A3_E2(s0, 6, p0b.h[2]);
+  A3_E2(s0, 7, p0b.h[3]);
   A3_FENCE();
-  // ---- V0b | max1
+  // ---- V0b | row sum 0, max1
   oacc[0][0] = MFMA32(vb[0], p0b.v, oacc[0][0], 0, 0, 0);
+  A3_LADD(lrun[0], l0a, A3_SUM4(p0b));
   a3_mask<TAIL>(s1, key0, nkv, hh);
   a3_max<FIRST>(s1, oacc[1], negm[1], mrun[1], lrun[1]);
   A3_FENCE();
@@ -467,10 +477,11 @@ __device__ __forceinline__ void attn3_block(const u16* sK, const u16* sV, int kb
 // after the wave's last block: chain 1's pending exp / P.V
 __device__ __forceinline__ void attn3_drain(f32x16 (&oacc)[2][2], float (&lrun)[2], const f32x16& s1, const hx8 (&va)[2], const hx8 (&vb)[2]) {
   A3P p1a, p1b;
-  A3_E2(s1, 0, p1a.h[0], lrun[1]); A3_E2(s1, 1, p1a.h[1], lrun[1]); A3_E2(s1, 2, p1a.h[2], lrun[1]); A3_E2(s1, 3, p1a.h[3], lrun[1]);
+  A3_E2(s1, 0, p1a.h[0]); A3_E2(s1, 1, p1a.h[1]); A3_E2(s1, 2, p1a.h[2]); A3_E2(s1, 3, p1a.h[3]);
   oacc[1][0] = MFMA32(va[0], p1a.v, oacc[1][0], 0, 0, 0);
   oacc[1][1] = MFMA32(va[1], p1a.v, oacc[1][1], 0, 0, 0);
-  A3_E2(s1, 4, p1b.h[0], lrun[1]); A3_E2(s1, 5, p1b.h[1], lrun[1]); A3_E2(s1, 6, p1b.h[2], lrun[1]); A3_E2(s1, 7, p1b.h[3], lrun[1]);
+  A3_E2(s1, 4, p1b.h[0]); A3_E2(s1, 5, p1b.h[1]); A3_E2(s1, 6, p1b.h[2]); A3_E2(s1, 7, p1b.h[3]);
+  A3_LADD(lrun[1], A3_SUM4(p1a), A3_SUM4(p1b));
   oacc[1][0] = MFMA32(vb[0], p1b.v, oacc[1][0], 0, 0, 0);
   oacc[1][1] = MFMA32(vb[1], p1b.v, oacc[1][1], 0, 0, 0);
 }
@@ -831,10 +842,11 @@ __global__ __launch_bounds__(512, 2) void attn64pp_kernel(const AttnParams p) {
     _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                       \
       a3_mask<TAIL_>(sc[qb], key0, p.nkv, hh);                                                               \
       a3_max<FIRST_>(sc[qb], oacc[qb], negm[qb], mrun[qb], lrun[qb]);                                        \
-      A3_E2(sc[qb], 0, pb[qb][0].h[0], lrun[qb]); A3_E2(sc[qb], 1, pb[qb][0].h[1], lrun[qb]);                \
-      A3_E2(sc[qb], 2, pb[qb][0].h[2], lrun[qb]); A3_E2(sc[qb], 3, pb[qb][0].h[3], lrun[qb]);                \
-      A3_E2(sc[qb], 4, pb[qb][1].h[0], lrun[qb]); A3_E2(sc[qb], 5, pb[qb][1].h[1], lrun[qb]);                \
-      A3_E2(sc[qb], 6, pb[qb][1].h[2], lrun[qb]); A3_E2(sc[qb], 7, pb[qb][1].h[3], lrun[qb]);                \
+      A3_E2(sc[qb], 0, pb[qb][0].h[0]); A3_E2(sc[qb], 1, pb[qb][0].h[1]);                                    \
+      A3_E2(sc[qb], 2, pb[qb][0].h[2]); A3_E2(sc[qb], 3, pb[qb][0].h[3]);                                    \
+      A3_E2(sc[qb], 4, pb[qb][1].h[0]); A3_E2(sc[qb], 5, pb[qb][1].h[1]);                                    \
+      A3_E2(sc[qb], 6, pb[qb][1].h[2]); A3_E2(sc[qb], 7, pb[qb][1].h[3]);                                    \
+      A3_LADD(lrun[qb], A3_SUM4(pb[qb][0]), A3_SUM4(pb[qb][1]));                                             \
     }                                                                                                        \
     _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                                         \
       asm volatile("" : "+v"(pb[qb][0].v), "+v"(pb[qb][1].v), "+v"(negm[qb]), "+v"(lrun[qb]), "+v"(oacc[qb][0]), "+v"(oacc[qb][1])); \
