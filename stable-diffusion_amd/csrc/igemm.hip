@@ -584,8 +584,19 @@ __device__ __forceinline__ void igemm_finish(const IgemmParams& p, f32x4 (&acc)[
 // BUF (GEMM only, K % 64 == 0): staging through buffer descriptors (dma_buf16): a lane's byte offset inside the block's A / W
 // panel is computed once, the K position is a scalar offset, rows past M / N carry an out-of-range offset (zeros) and K-tiles
 // past the end go through a descriptor of zero records - no vector instruction in the K loop's staging at all.
+// Diagnostic build only (make EXTRA=-DIGEMM_STAMP LIB=<another file>; scratch/r3/igemm_stamps.py reads the stamps): wave 0 of
+// every block leaves s_memrealtime (100 MHz) at 0 kernel start, 5 tile decode done, 6 epilogue operands requested, 7 first
+// DMAs issued, 1 prologue done, 2 first K-tile landed, 3 K loop done, 4 stores retired.
+#ifdef IGEMM_STAMP
+__device__ unsigned long long g_igemm_stamp[8192 * 8];
+extern "C" int sdmi_debug_igemm_stamps(void* dst, int bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_igemm_stamp), bytes); }
+#define IG_STAMP(I) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0 && blockIdx.x < 8192) g_igemm_stamp[blockIdx.x * 8 + (I)] = t_; }
+#else
+#define IG_STAMP(I)
+#endif
 template <int BM, int BN, int WM, int WN, bool CONV, int NSTAGE, bool GEGLU, bool BUF = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) * BK * 2 <= 80 * 1024 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
+  IG_STAMP(0);
   static_assert(!(BUF && CONV), "buffer-descriptor staging: GEMM only");
   constexpr int NTH = 64 * WM * WN, RP = NTH / 8;          // threads; tile rows staged per DMA pass
   constexpr int TM = BM / WM, TN = BN / WN;                // wave tile
@@ -764,9 +775,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
   constexpr bool FAST_OK = !GEGLU || TN >= 64;
   EpiRegs<TM, FAST_OK ? TN : 64, GEGLU> er;
   const bool fast = FAST_OK && p.fast_epi;
+  IG_STAMP(5);
   if constexpr (FAST_OK) if (fast && p.splits == 1) epi_prefetch<TM, TN, GEGLU>(p, er, bz, brow + wr * TM, bcol + wc * TN, lane);
+  IG_STAMP(6);
 #pragma unroll
   for (int sidx = 0; sidx < NSTAGE; ++sidx) IGEMM_STAGE_TILE(kt_begin + sidx, sidx);
+  IG_STAMP(7);
   // LayerNorm folded into this GEMM (SDMI_F_LNFOLD): per-row (mean, rstd) from the producer's row partials and this tile's
   // column sums u go to a side region of the LDS, behind the ring (same array: one LDS object).  Placed AFTER the prologue's
   // DMA issue: the loads' latency then overlaps the wait for the first K-tile (in front of it, it delayed the whole
@@ -825,7 +839,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
       for (int c = t; c < BN; c += NTH) lnside[2 * BM + c] = bcol + c < p.N ? p.ln_u[bcol + c] : 0.f;
     }
   }
+  IG_STAMP(1);
   IGEMM_WAIT_STAGE(NSTAGE - 1);  // tile kt_begin has landed, NSTAGE-1 younger ones are in flight
+  IG_STAMP(2);
   IGEMM_READ_FRAGS(af0, wf0, 0, 0);
   int slot = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -846,8 +862,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE * (BM + BN) *
 #undef IGEMM_WAIT_STAGE
 #undef IGEMM_GLDS
 
+  IG_STAMP(3);
   igemm_finish<TM, TN, GEGLU, !CONV, true>(p, acc, er, fast, smem, bz, brow + wr * TM, bcol + wc * TN, (lds_cfp)lnside, BM, wr * TM, wc * TN,
                               (brow + wr * TM) / 32, (bcol + wc * TN) / 32);
+#ifdef IGEMM_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  IG_STAMP(4);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ persistent plain GEMM
