@@ -163,6 +163,12 @@ typedef struct sdmi_epilogue_ext {
   const float* ln_u;        /* SDMI_F_LNFOLD: [N] in packed row order (sdmi_pack_linear_ln) */
   int ln_parts;
   float ln_eps;
+  const float* gn_in;       /* sdmi_conv3x3_ex only, with SDMI_F_SILU: x is the RAW tensor and this is its GroupNorm table, fp32
+                             * [n][cin][2] = (scale, shift) per sample and channel (sdmi_groupnorm_colstats_finalize or
+                             * sdmi_groupnorm_stats); the conv computes conv(SiLU(x * scale + shift)) - the GN + SiLU + conv of
+                             * layers/ResBlock.py:65-67, :72-74 and AutoencoderKL.py:193-194 in ONE pass over x, bit-identical to
+                             * sdmi_groupnorm_apply followed by the plain conv.  Only where one 128-column block covers all output
+                             * channels: stride 1, pad 1, cout <= 128, cin % 64 == 0, h*w % 128 == 0; other shapes are an error. */
 } sdmi_epilogue_ext;
 int sdmi_gemm_ex(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
                  int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
@@ -172,6 +178,8 @@ int sdmi_conv3x3_ex(const void* x, int ldx, int n, int h, int w, int cin, const 
                     int hout, int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias,
                     int ldrb, const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* ws, int64_t ws_bytes,
                     void* stream, const sdmi_epilogue_ext* ext);
+/* 1 when sdmi_conv3x3_ex can take sdmi_epilogue_ext.gn_in for this stride-1 pad-1 same-size conv (input row stride ldx), else 0 */
+int sdmi_conv3x3_gn_in_ok(int n, int h, int w, int cin, int cout, int ldx);
 /* parts of the statistics the calls above write for this problem: *row_parts (colstats) and *col_parts (rowstats); 0 where
  * the problem cannot emit them.  Either pointer may be NULL.  (upsample: SDMI_F_UPSAMPLE2X in flags) */
 int sdmi_gemm_stats_parts(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags, int* row_parts, int* col_parts);
@@ -183,6 +191,10 @@ int sdmi_conv3x3_stats_parts(int n, int h, int w, int cin, int cout, int hout, i
  * [sample * seg_parts[s] + part][seg_ld[s]][2] (seg_parts = row parts PER SAMPLE = hw / 32, seg_ld = the producer's N) and
  * the segment's channels start at column seg_col0[s] of it.  scale_shift: scratch of sdmi_groupnorm_colstats_ss_bytes(). */
 int64_t sdmi_groupnorm_colstats_ss_bytes(int n, int c, int groups);
+/* the fold alone: scale_shift[n][c][2] from the producers' colstats, no apply pass (for sdmi_epilogue_ext.gn_in) */
+int sdmi_groupnorm_colstats_finalize(int n, int hw, int c, int groups, const float* gamma, const float* beta, float eps, int nseg,
+                                     const float* const* seg_stats, const int* seg_parts, const int* seg_ld, const int* seg_col0,
+                                     const int* seg_c0, const int* seg_c, float* scale_shift, void* stream);
 int sdmi_groupnorm_from_colstats(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups,
                                  const float* gamma, const float* beta, float eps, uint32_t flags, int nseg,
                                  const float* const* seg_stats, const int* seg_parts, const int* seg_ld, const int* seg_col0,

@@ -18,7 +18,7 @@ F_WS_TICKETS = 1024
 class EpilogueExt(C.Structure):
     """sdmi_epilogue_ext (include/sdmi.h)."""
     _fields_ = [("colstats", C.c_void_p), ("rowstats", C.c_void_p), ("ln_rowstats", C.c_void_p), ("ln_u", C.c_void_p),
-                ("ln_parts", C.c_int), ("ln_eps", C.c_float)]
+                ("ln_parts", C.c_int), ("ln_eps", C.c_float), ("gn_in", C.c_void_p)]
 
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -50,10 +50,12 @@ PROTOTYPES = {
     "sdmi_gemm_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _u32]),
     "sdmi_gemm_ex": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp, _i64, _vp, _vp]),
     "sdmi_conv3x3_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp, _i64, _vp, _vp]),
+    "sdmi_conv3x3_gn_in_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "sdmi_gemm_stats_parts": (_i, [_i, _i, _i, _i, _i, _u32, _vp, _vp]),
     "sdmi_conv3x3_stats_parts": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u32, _vp]),
     "sdmi_groupnorm_from_colstats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdmi_groupnorm_colstats_ss_bytes": (_i64, [_i, _i, _i]),
+    "sdmi_groupnorm_colstats_finalize": (_i, [_i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdmi_pack_linear_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sdmi_tune_override": (None, [_i, _i]),
     "sdmi_tune_conv_window": (None, [_i]),

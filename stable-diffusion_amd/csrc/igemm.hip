@@ -45,6 +45,8 @@ struct IgemmParams {
   const float* ln_u;       // LNFOLD: [N] column sums of the packed weights
   int ln_parts, col_parts;
   float ln_eps;
+  // GroupNorm + SiLU of the INPUT applied to the staged windows (sdmi_epilogue_ext.gn_in; conv_win2_kernel<.., GNA = true>)
+  const float* gn_ss;      // [sample][Cin][2] (scale, shift) of the raw input a
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};  // non-const: stays in the global address space (no flat loads)
@@ -1410,7 +1412,14 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(const IgemmParams p) {
 __device__ __forceinline__ int lds_off_w(int row, int chunk) { return row * BK + ((chunk ^ (((row >> 1) & 3) << 1)) << 3); }
 // (Tried and dropped, profiles/r03_conv_win2_ab.txt: scheduling fences that keep a step's fragment reads in front of the
 // previous step's MFMAs, and s_setprio around the MFMA batches - 178 VGPRs instead of 154, 1.5 ... 4 % slower.)
-template <int BM, int BN, bool CS>
+// GNA (north-star item (b), the bounded case; sdmi_epilogue_ext.gn_in): the input is the RAW tensor and a per-(sample, channel)
+// scale / shift table; every staged window is turned into SiLU(x * scale + shift) in place before the MFMAs read it - by the
+// thread that staged the 16-byte piece (it waits for its own DMA, transforms, and the K loop's barrier publishes the result;
+// no extra barrier), padding rows (zero-filled by the descriptor) left alone.  Same expression as gn_apply_kernel
+// (fma, silu_f, saturating pack): the LDS holds the same bits the unfused pair would have staged, so the result is
+// bit-identical to sdmi_groupnorm_apply + this kernel.  One column block only (Cout <= BN, host): a second column block
+// would transform the same windows again.
+template <int BM, int BN, bool CS, bool GNA = false>
 __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_win2_kernel(const IgemmParams p) {
   constexpr int TM = BM / 2, TN = BN / 2, MT = TM / 16, NT = TN / 16;
   constexpr int WROWS = BM + 8;           // staged window rows: BM + 2 are read; whole 8-row DMA instructions
@@ -1441,7 +1450,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
     const int r = r0 + 32 * i, q = brow - 1 + r;  // window row r holds pixel q (flat N*H*W index)
-    const bool ok = r < WROWS && q >= 0 && q < p.M;
+    const bool ok = r < BM + 2 && q >= 0 && q < p.M;  // rows BM + 2 ... of the last 8-row DMA group are never read: not fetched
     const int qc = ok ? q : 0;
     const int img = qc / hw, y = (qc - img * hw) / p.W;
     w_mask[i] = ok ? ((y >= 1 ? 1 : 0) | 2 | (y <= p.H - 2 ? 4 : 0)) : 0;
@@ -1478,6 +1487,33 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
   int s_cb = kt_begin / 9, s_tap = kt_begin - s_cb * 9, s_kt = kt_begin;  // next weight tile to stage
   int w_cb = s_cb, w_ky = s_tap / 3;                                        // next window to stage
   const int row_bytes = p.W * p.lda * 2;                                    // one image row of the input
+  // GNA: this thread's 8 channels of the chunk whose windows are being transformed, and the next window to transform
+  [[maybe_unused]] float gsc[8], gsh[8];
+  [[maybe_unused]] const float* gn_tab = nullptr;
+  [[maybe_unused]] int g_ky = w_ky;
+  if constexpr (GNA) gn_tab = p.gn_ss + ((long long)(brow / hw) * p.Cin + lchunk * 8) * 2;
+#define WIN2_GN_LOAD(CB)                                                                                  \
+  if constexpr (GNA) {                                                                                    \
+    const f32x4* sp = (const f32x4*)(gn_tab + (CB) * (BK * 2));                                           \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+      const f32x4 v = sp[e];                                                                              \
+      gsc[2 * e] = v[0]; gsh[2 * e] = v[1]; gsc[2 * e + 1] = v[2]; gsh[2 * e + 1] = v[3];                 \
+    }                                                                                                     \
+  }
+#define WIN2_GN_APPLY(WBI)                                                                                \
+  if constexpr (GNA) {                                                                                    \
+    const int kbit = 1 << g_ky;                                                                           \
+    _Pragma("unroll") for (int i = 0; i < PW; ++i) {                                                      \
+      if (wave_row0 + 32 * i < WROWS && (w_mask[i] & kbit)) {                                             \
+        uint4* q = (uint4*)(smem + (WBI) * WBUF + (r0 + 32 * i) * BK + (t & 7) * 8);                      \
+        float f[8];                                                                                       \
+        unpack8(*q, f);                                                                                   \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) f[e] = silu_f(__builtin_fmaf(f[e], gsc[e], gsh[e])); \
+        *q = pack8(f);                                                                                    \
+      }                                                                                                   \
+    }                                                                                                     \
+    if (++g_ky == 3) g_ky = 0;                                                                            \
+  }
 
 #define WIN2_STAGE_W(WBI)                                                                                 \
   {                                                                                                       \
@@ -1526,25 +1562,35 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
   const bool fast = p.fast_epi;
   if (fast && p.splits == 1) epi_prefetch<TM, TN, false>(p, er, 0, brow + wr * TM, bcol + wc * TN, lane);
 
+  WIN2_GN_LOAD(w_cb);
   WIN2_STAGE_W(0);
   WIN2_STAGE_B(0);
   WIN2_STAGE_B(1);
+  if constexpr (GNA) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's own pieces have landed
+    WIN2_GN_APPLY(0);
+  }
   WIN2_WAIT();
   WIN2_READ(af0, wf0, smem, 0, 0, 0);
-  // group structure: see conv_win_kernel
+  // group structure: see conv_win_kernel.  GNA: the next window is staged after the first barrier of a group, has landed at
+  // the second (vmcnt(0)), is transformed behind it by the threads that staged it, and is first read after the third.
 #define WIN2_GROUP(WCUR, WNEXT, WNI, S0, S1)                                                   \
   {                                                                                            \
     WIN2_READ(af1, wf1, WCUR, 0, 1, S0);                                                       \
     WIN2_MFMA(af0, wf0);                                                                       \
     WIN2_WAIT();                                                                               \
     WIN2_STAGE_B(S0);                                                                          \
-    if (kt + 3 < kt_end) WIN2_STAGE_W(WNI);                                                    \
+    if (kt + 3 < kt_end) {                                                                     \
+      if (w_ky == 0) WIN2_GN_LOAD(w_cb);                                                       \
+      WIN2_STAGE_W(WNI);                                                                       \
+    }                                                                                          \
     WIN2_READ(af0, wf0, WCUR, 1, 0, S1);                                                       \
     WIN2_MFMA(af1, wf1);                                                                       \
     WIN2_READ(af1, wf1, WCUR, 1, 1, S1);                                                       \
     WIN2_MFMA(af0, wf0);                                                                       \
     WIN2_WAIT();                                                                               \
     WIN2_STAGE_B(S1);                                                                          \
+    if (kt + 3 < kt_end) WIN2_GN_APPLY(WNI);                                                   \
     WIN2_READ(af0, wf0, WCUR, 2, 0, S0);                                                       \
     WIN2_MFMA(af1, wf1);                                                                       \
     WIN2_READ(af1, wf1, WCUR, 2, 1, S0);                                                       \
@@ -1562,6 +1608,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
   }
 #undef WIN2_GROUP
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef WIN2_GN_LOAD
+#undef WIN2_GN_APPLY
 #undef WIN2_STAGE_W
 #undef WIN2_STAGE_B
 #undef WIN2_WAIT
@@ -1856,10 +1904,18 @@ static void stats_parts_of(const IgemmParams& p, int batch, int vi, int* row_par
   if (col_parts) *col_parts = (plain && p.N % 32 == 0) ? p.N / 32 : 0;
 }
 
+// sdmi_epilogue_ext.gn_in: what the planned launch must be (128 x 128 window tiles of the round-3 kernel, one column block, row
+// tiles inside one sample)
+static bool gn_in_ok(const IgemmParams& p, int vi, int batch) {
+  static int win_env = -1;
+  if (win_env < 0) { const char* e = getenv("SDMI_CONV_WIN"); win_env = (e && e[0] == '0') ? 0 : 1; }
+  return vi == 1 && p.N <= 128 && p.splits == 1 && batch == 1 && p.rows_per_sample % 128 == 0 && conv_window_shape(p, batch) &&
+         conv_win2_ok(p, 128) && (g_force_window >= 0 ? g_force_window : win_env) != 0;
+}
 // conv_win2_kernel launch; > 64 KB of dynamic LDS allowed once per device
-template <int BM, int BN, bool CS>
+template <int BM, int BN, bool CS, bool GNA = false>
 static void launch_win2_cs(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
-  auto kfn = conv_win2_kernel<BM, BN, CS>;
+  auto kfn = conv_win2_kernel<BM, BN, CS, GNA>;
   static unsigned long long attr_done = 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1874,6 +1930,11 @@ static void launch_win2(dim3 grid, int bytes, hipStream_t st, const IgemmParams&
   if (p.colstats) launch_win2_cs<BM, BN, true>(grid, bytes, st, p);
   else launch_win2_cs<BM, BN, false>(grid, bytes, st, p);
 }
+// GroupNorm + SiLU of the input applied to the staged windows (128 x 128 tiles, one column block)
+static void launch_win2_gn(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
+  if (p.colstats) launch_win2_cs<128, 128, true, true>(grid, bytes, st, p);
+  else launch_win2_cs<128, 128, false, true>(grid, bytes, st, p);
+}
 
 template <bool CONV>
 static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st, const sdmi_epilogue_ext* ext = nullptr) {
@@ -1884,7 +1945,22 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
   const int bm = tv.bm, bn = tv.bn;
   const int nb = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   p.colstats = nullptr; p.rowstats = nullptr; p.ln_stats = nullptr; p.ln_u = nullptr; p.ln_parts = 0; p.col_parts = 0; p.ln_eps = 0.f;
+  p.gn_ss = nullptr;
   float* split_colstats = nullptr;
+  if (ext && ext->gn_in) {
+    // the conv applies GroupNorm + SiLU to its input itself: only where ONE block column covers every output channel (else
+    // each column block would transform the same staged windows again) on the round-3 shared-window kernel, and never
+    // silently on another path
+    SDMI_REQUIRE(CONV, "gemm: gn_in is a conv3x3 mode");
+    SDMI_REQUIRE(p.flags & SDMI_F_SILU, "conv3x3: gn_in applies GroupNorm + SiLU; pass SDMI_F_SILU");
+    SDMI_REQUIRE(((uintptr_t)ext->gn_in & 15) == 0, "conv3x3: gn_in must be 16-byte aligned");
+    SDMI_REQUIRE(gn_in_ok(p, vi, batch),
+                 "conv3x3: gn_in needs a stride-1 pad-1 conv with Cout <= 128, Cin %% 64 == 0, H*W %% 128 == 0 on 128 x 128 window tiles "
+                 "(cin=%d cout=%d hw=%d variant=%d splits=%d)", p.Cin, p.N, p.rows_per_sample, vi, p.splits);
+    p.gn_ss = ext->gn_in;
+  } else {
+    SDMI_REQUIRE(!CONV || !(p.flags & SDMI_F_SILU), "conv3x3: SDMI_F_SILU without sdmi_epilogue_ext.gn_in");
+  }
   if (ext) {
     int rparts = 0, cparts = 0;
     stats_parts_of(p, batch, vi, &rparts, &cparts);
@@ -1957,7 +2033,9 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
           (void)hipFuncSetAttribute((const void*)conv_win_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes128);
           attr_done |= 1ull << (dev & 63);
         }
-        if (v2) {
+        if (p.gn_ss) {
+          launch_win2_gn(grid, wbytes128, st, p);
+        } else if (v2) {
           launch_win2<128, 128>(grid, wbytes128, st, p);
         } else {
           if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 128, true>), grid, dim3(256), wbytes128, st, p);
@@ -1969,7 +2047,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 64, true>), grid, dim3(256), wbytes64, st, p);
         else hipLaunchKernelGGL((conv_win_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);
       }
-      sdmi_note_kernel("%s<%d, %d, %s>%s", v2 ? "conv_win2_kernel" : "conv_win_kernel", bm, bn, p.colstats ? "true" : "false",
+      sdmi_note_kernel("%s<%d, %d, %s%s>%s", v2 ? "conv_win2_kernel" : "conv_win_kernel", bm, bn, p.colstats ? "true" : "false", p.gn_ss ? ", true" : "",
                        (p.splits > 1 && !p.ticket) ? (split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
       int rcw = sdmi_check_launch("conv3x3 (shared window)");
       if (rcw || p.splits < 2 || p.ticket) return rcw;
@@ -1982,6 +2060,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
       return sdmi_check_launch("split-K reduce");
     }
   }
+  SDMI_REQUIRE(!p.gn_ss, "conv3x3: gn_in is only available on the shared-window kernel (SDMI_CONV_WIN=0 or a forced variant is set)");
   // A-stationary blocks for short-K GEMMs with many column tiles per row tile: opt-in (gemm_astat = 1).  Same bits, half the
   // staged bytes, and 14-35 % SLOWER on every K = 320 GEMM tried (profiles/r03_gemm_astat_ab.txt: 9216 x 2560 x 320 GEGLU
   // 40.1 against 29.5 us): at one block per CU and one wave per SIMD a tile's K loop (five barrier-separated K-tiles) and
@@ -2160,6 +2239,14 @@ extern "C" int sdmi_conv3x3_stats_parts(int n, int h, int w, int cin, int cout, 
   const int vi = plan_igemm<true>(p, 1, true, (int64_t)1 << 62);
   stats_parts_of(p, 1, vi, row_parts, nullptr);
   return SDMI_OK;
+}
+
+extern "C" int sdmi_conv3x3_gn_in_ok(int n, int h, int w, int cin, int cout, int ldx) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ldx < cin) return 0;
+  IgemmParams p;
+  conv_params(p, nullptr, ldx, n, h, w, cin, nullptr, cout, h, w, 1, 1, 1, nullptr, nullptr, 0, nullptr, 0, nullptr, cout, SDMI_F_SILU);
+  const int vi = plan_igemm<true>(p, 1, true, (int64_t)1 << 62);
+  return gn_in_ok(p, vi, 1) ? 1 : 0;
 }
 
 extern "C" int sdmi_conv3x3_ex(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout, int hout,

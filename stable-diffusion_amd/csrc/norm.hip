@@ -547,13 +547,13 @@ extern "C" int64_t sdmi_groupnorm_colstats_ss_bytes(int n, int c, int groups) {
   return ((int64_t)n * c * 2 * (int64_t)sizeof(float) + 15) / 16 * 16 + (int64_t)n * groups * GNF_MAX_CHUNKS * 2 * (int64_t)sizeof(double);
 }
 
-extern "C" int sdmi_groupnorm_from_colstats(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups,
-                                            const float* gamma, const float* beta, float eps, uint32_t flags, int nseg,
-                                            const float* const* seg_stats, const int* seg_parts, const int* seg_ld,
-                                            const int* seg_col0, const int* seg_c0, const int* seg_c, float* scale_shift,
-                                            void* stream) {
-  SDMI_REQUIRE(x && y && gamma && beta && scale_shift && seg_stats && seg_parts && seg_ld && seg_col0 && seg_c0 && seg_c,
+extern "C" int sdmi_groupnorm_colstats_finalize(int n, int hw, int c, int groups, const float* gamma, const float* beta, float eps, int nseg,
+                                                const float* const* seg_stats, const int* seg_parts, const int* seg_ld,
+                                                const int* seg_col0, const int* seg_c0, const int* seg_c, float* scale_shift,
+                                                void* stream) {
+  SDMI_REQUIRE(gamma && beta && scale_shift && seg_stats && seg_parts && seg_ld && seg_col0 && seg_c0 && seg_c,
                "groupnorm_from_colstats: null pointer");
+  SDMI_REQUIRE(((uintptr_t)scale_shift & 15) == 0, "groupnorm_from_colstats: scale_shift must be 16-byte aligned");
   SDMI_REQUIRE(n > 0 && hw > 0 && c > 0 && groups > 0 && c % groups == 0 && n <= 65535, "groupnorm_from_colstats: bad shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
   SDMI_REQUIRE(c / groups <= 256, "groupnorm_from_colstats: more than 256 channels per group");
   SDMI_REQUIRE(nseg == 1 || nseg == 2, "groupnorm_from_colstats: 1 or 2 segments");
@@ -587,6 +587,18 @@ extern "C" int sdmi_groupnorm_from_colstats(const void* x, int ldx, void* y, int
     rc = sdmi_check_launch("groupnorm finalize (chunks)");
     if (rc) return rc;
   }
+  return SDMI_OK;
+}
+
+extern "C" int sdmi_groupnorm_from_colstats(const void* x, int ldx, void* y, int ldy, int n, int hw, int c, int groups,
+                                            const float* gamma, const float* beta, float eps, uint32_t flags, int nseg,
+                                            const float* const* seg_stats, const int* seg_parts, const int* seg_ld,
+                                            const int* seg_col0, const int* seg_c0, const int* seg_c, float* scale_shift,
+                                            void* stream) {
+  SDMI_REQUIRE(x && y, "groupnorm_from_colstats: null pointer");
+  const int rc = sdmi_groupnorm_colstats_finalize(n, hw, c, groups, gamma, beta, eps, nseg, seg_stats, seg_parts, seg_ld, seg_col0, seg_c0,
+                                                  seg_c, scale_shift, stream);
+  if (rc) return rc;
   return sdmi_groupnorm_apply(x, ldx, scale_shift, y, ldy, n, hw, c, flags, stream);
 }
 

@@ -40,12 +40,13 @@ class Act(object):
     stats: {column offset: (colstats tensor, row parts per sample, channels)} left by the kernels that produced column
     ranges of the buffer (shared by every view of it): per-channel sums for the GroupNorm that follows.
     rstats: (rowstats tensor, column parts) left by the GEMM that produced this view: per-row sums for a LayerNorm."""
-    __slots__ = ("buf", "n", "h", "w", "c", "off", "stats", "rstats")
+    __slots__ = ("buf", "n", "h", "w", "c", "off", "stats", "rstats", "gn")
 
     def __init__(self, buf, n, h, w, c, off=0, stats=None):
         self.buf, self.n, self.h, self.w, self.c, self.off = buf, n, h, w, c, off
         self.stats = {} if stats is None else stats
         self.rstats = None
+        self.gn = None      # pending GroupNorm + SiLU: the (n, c, 2) scale/shift table the consuming conv applies itself
 
     @property
     def hw(self):
@@ -248,6 +249,9 @@ def _audit(what, res):
 # --------------------------------------------------------------------------- ops
 USE_COLSTATS = os.environ.get("SDMI_COLSTATS", "1") == "1"     # GroupNorm statistics from the producer's epilogue (A/B switch)
 USE_LNFOLD = os.environ.get("SDMI_LNFOLD", "1") == "1"         # LayerNorm folded into the GEMM that follows it (A/B switch)
+# GroupNorm + SiLU applied by the consuming conv to its staged input (north-star item (b)); only convs whose one block column
+# covers every output channel qualify (the VAE's 128-channel level).  Default from the measurement in DESIGN.md section 5.
+GN_IN_CONV = os.environ.get("SDMI_GN_IN_CONV", "0") == "1"
 
 
 def _gn_small(hw, c, groups):
@@ -269,30 +273,47 @@ def _stat_segments(a):
     return segs if pos == a.off + a.c else None
 
 
-def groupnorm(a, weight, bias, eps, silu, groups=32):
+def groupnorm(a, weight, bias, eps, silu, groups=32, conv_cout=None):
     """GroupNorm(+SiLU): one fused launch when a (sample, group) slice fits a block; else, when the kernels that produced
-    `a` left per-channel statistics (colstats), a fold of those + apply; else stats + apply (csrc/norm.hip)."""
+    `a` left per-channel statistics (colstats), a fold of those + apply; else stats + apply (csrc/norm.hip).
+    conv_cout: the result feeds ONLY a stride-1 pad-1 3x3 conv with that many output channels; where that conv can apply the
+    normalisation to its own staged input (sdmi_epilogue_ext.gn_in, GN_IN_CONV) the apply pass is skipped: the returned view
+    is the RAW tensor carrying the scale/shift table (Act.gn), which conv3x3 hands to the kernel."""
     dev = a.device
-    segs = _stat_segments(a) if (USE_COLSTATS and not _gn_small(a.hw, a.c, groups)) else None
+    small = _gn_small(a.hw, a.c, groups)
+    segs = _stat_segments(a) if (USE_COLSTATS and not small) else None
+    defer = (GN_IN_CONV and conv_cout is not None and silu and not small and
+             L.load().sdmi_conv3x3_gn_in_ok(a.n, a.h, a.w, a.c, conv_cout, a.ld) == 1)
     if segs is not None:
         import ctypes as C
         ns = len(segs)
         ss = torch.empty((L.load().sdmi_groupnorm_colstats_ss_bytes(a.n, a.c, groups) // 4,), dtype=torch.float32, device=dev)
-        y = new_act(a.n, a.h, a.w, a.c, dev)
         ptrs = (C.c_void_p * 2)(*[t.data_ptr() for t, _, _ in segs] + [0] * (2 - ns))
         ivec = lambda v: (C.c_int * 2)(*(list(v) + [0] * (2 - ns)))
         c0, acc = [], 0
         for _, _, cc in segs:
             c0.append(acc)
             acc += cc
-        L.call("sdmi_groupnorm_from_colstats", a.ptr, a.ld, y.ptr, y.ld, a.n, a.hw, a.c, groups,
-               _f32c(weight, "gn weight").data_ptr(), _f32c(bias, "gn bias").data_ptr(), float(eps), L.F_SILU if silu else 0, ns,
-               C.cast(ptrs, C.c_void_p), C.cast(ivec(p for _, p, _ in segs), C.c_void_p), C.cast(ivec(cc for _, _, cc in segs), C.c_void_p),
-               C.cast(ivec([0] * ns), C.c_void_p), C.cast(ivec(c0), C.c_void_p), C.cast(ivec(cc for _, _, cc in segs), C.c_void_p),
-               ss.data_ptr(), _stream())
+        seg_args = (ns, C.cast(ptrs, C.c_void_p), C.cast(ivec(p for _, p, _ in segs), C.c_void_p), C.cast(ivec(cc for _, _, cc in segs), C.c_void_p),
+                    C.cast(ivec([0] * ns), C.c_void_p), C.cast(ivec(c0), C.c_void_p), C.cast(ivec(cc for _, _, cc in segs), C.c_void_p),
+                    ss.data_ptr(), _stream())
+        gb = (_f32c(weight, "gn weight").data_ptr(), _f32c(bias, "gn bias").data_ptr(), float(eps))
+        if defer:
+            L.call("sdmi_groupnorm_colstats_finalize", a.n, a.hw, a.c, groups, *(gb + seg_args))
+            y = Act(a.buf, a.n, a.h, a.w, a.c, a.off, a.stats)
+            y.gn = ss
+            return y
+        y = new_act(a.n, a.h, a.w, a.c, dev)
+        L.call("sdmi_groupnorm_from_colstats", a.ptr, a.ld, y.ptr, y.ld, a.n, a.hw, a.c, groups, *(gb + (L.F_SILU if silu else 0,) + seg_args))
         return y
     ss = torch.empty((a.n, a.c, 2), dtype=torch.float32, device=dev)
     ws = torch.empty((L.load().sdmi_groupnorm_ws_bytes(a.n, a.hw, a.c) // 4,), dtype=torch.float32, device=dev)
+    if defer:
+        L.call("sdmi_groupnorm_stats", a.ptr, a.n, a.hw, a.c, a.ld, groups, _f32c(weight, "gn weight").data_ptr(),
+               _f32c(bias, "gn bias").data_ptr(), float(eps), ss.data_ptr(), ws.data_ptr(), _stream())
+        y = Act(a.buf, a.n, a.h, a.w, a.c, a.off, a.stats)
+        y.gn = ss
+        return y
     y = new_act(a.n, a.h, a.w, a.c, dev)
     L.call("sdmi_groupnorm", a.ptr, a.ld, y.ptr, y.ld, a.n, a.hw, a.c, groups, _f32c(weight, "gn weight").data_ptr(),
            _f32c(bias, "gn bias").data_ptr(), float(eps), L.F_SILU if silu else 0, ss.data_ptr(), ws.data_ptr(), _stream())
@@ -314,6 +335,8 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
     if cin != a.c:
         raise L.SdmiError("conv3x3: input has %d channels, weight expects %d" % (a.c, cin))
     pl, pr, pt, pb = pad
+    if a.gn is not None and (stride != 1 or upsample or tuple(pad) != (1, 1, 1, 1)):
+        raise L.SdmiError("conv3x3: the input carries a pending GroupNorm (Act.gn) that only a stride-1 pad-1 conv can apply")
     hin, win = (a.h * 2, a.w * 2) if upsample else (a.h, a.w)
     ho = (hin + pt + pb - 3) // stride + 1
     wo = (win + pl + pr - 3) // stride + 1
@@ -361,6 +384,10 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
             res.stats[res.off] = (cs, rp.value // a.n, cout)
     if ext is None and isinstance(res, Act):
         res.stats.pop(res.off, None)
+    if a.gn is not None:
+        flags |= L.F_SILU
+        ext = ext or L.EpilogueExt()
+        ext.gn_in = a.gn.data_ptr()
     L.call("sdmi_conv3x3_ex", a.ptr, a.ld, a.n, a.h, a.w, cin, wp.data_ptr(), cout, ho, wo, stride, pt, pl,
            _ptr(bias), rb_ptr, ldrb, res_ptr, ldr, optr, ldc, flags | (WS_FLAGS if ws else 0), ws, wsb, _stream(),
            ctypes.addressof(ext) if ext is not None else 0)

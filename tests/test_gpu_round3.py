@@ -428,3 +428,102 @@ def test_attention_two_group_kernel_is_opt_in(attn_opts):
     attn_opts(0, 1)
     E.attention(a, a, a, 2, log2q=True)
     assert L.load().sdmi_last_kernel().decode() == "attn64pp_kernel"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# North-star item (b), the bounded case: GroupNorm + SiLU applied by the consuming conv to its staged windows
+# (sdmi_epilogue_ext.gn_in; conv_win2_kernel<128, 128, CS, GNA = true>).  Bit-identical to sdmi_groupnorm_apply + conv through
+# the engine and the VAE decoder; shapes the kernel cannot take are an error, never a silent other path.  Measured 3-7 %
+# slower than the unfused pair (profiles/r03_gn_in_conv_ab.txt), so engine.GN_IN_CONV is off by default.
+def _resblock_pair(n, hh, ww, cin, cout, seed, with_stats):
+    rs = np.random.RandomState(seed)
+    H = E.act_dtype()
+    x = T((rs.randn(n, hh * ww, cin) * 1.7 + 0.3).astype(np.float32)).to(DEV).to(H)
+    a = E.Act(x, n, hh, ww, cin)
+    gn = torch.nn.GroupNorm(32, cin).to(DEV)
+    gn.weight.data = T((1.0 + 0.3 * rs.randn(cin)).astype(np.float32)).to(DEV)
+    gn.bias.data = T((0.2 * rs.randn(cin)).astype(np.float32)).to(DEV)
+    W = torch.nn.Parameter(T((rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)).to(DEV))
+    B = torch.nn.Parameter(T(rs.randn(cout).astype(np.float32)).to(DEV))
+    res = E.Act(T(rs.randn(n, hh * ww, cout).astype(np.float32)).to(DEV).to(H), n, hh, ww, cout)
+    if with_stats:
+        # a producer that leaves colstats: identity-free path - run a 1x1 GEMM so `a` carries statistics
+        w0 = T((rs.randn(cin, cin) / np.sqrt(cin)).astype(np.float32)).to(DEV).to(H).contiguous()
+        a = E.gemm(a, w0, cin, colstats=True)
+        assert a.stats, "producer left no statistics"
+    return a, gn, W, B, res
+
+
+@pytest.mark.parametrize("n,hh,ww,cin,cout,with_stats", [(2, 112, 112, 128, 128, True), (1, 160, 160, 256, 128, True),
+                                                          (1, 192, 128, 128, 128, False), (3, 96, 96, 128, 128, True)])
+def test_conv_applies_groupnorm_silu_bit_identical(n, hh, ww, cin, cout, with_stats):
+    lib = L.load()
+    a, gn, W, B, res = _resblock_pair(n, hh, ww, cin, cout, hh + cin, with_stats)
+    assert lib.sdmi_conv3x3_gn_in_ok(n, hh, ww, cin, cout, a.ld) == 1
+    outs, kern = {}, {}
+    saved = E.GN_IN_CONV
+    for mode in (False, True):
+        E.GN_IN_CONV = mode
+        try:
+            h = E.groupnorm(a, gn.weight, gn.bias, gn.eps, silu=True, conv_cout=cout)
+            assert (h.gn is not None) == mode
+            o = E.conv3x3(h, W, B, residual=res)
+            kern[mode] = lib.sdmi_last_kernel().decode()
+            outs[mode] = (o.buf.clone(), o.stats[o.off][0].clone() if o.off in o.stats else None)
+        finally:
+            E.GN_IN_CONV = saved
+    torch.cuda.synchronize()
+    print(kern)
+    assert kern[True].startswith("conv_win2_kernel<128, 128") and kern[True].endswith(", true>")
+    assert torch.equal(outs[True][0].view(torch.int16), outs[False][0].view(torch.int16)), \
+        "fused GN+SiLU+conv differs from groupnorm_apply + conv: max %g" % float((outs[True][0].float() - outs[False][0].float()).abs().max())
+    if outs[False][1] is not None:
+        assert outs[True][1] is not None and torch.equal(outs[True][1], outs[False][1])
+    # and against the definition (fp32 torch): GN -> SiLU -> conv + residual
+    with torch.no_grad():
+        import torch.nn.functional as F
+        xf = a.buf[:, :, a.off:a.off + cin].float().reshape(n, hh, ww, cin).permute(0, 3, 1, 2)
+        ref = F.conv2d(F.silu(F.group_norm(xf, 32, gn.weight, gn.bias, gn.eps)), W, B, padding=1)
+        ref = ref.permute(0, 2, 3, 1).reshape(n, hh * ww, cout) + res.buf.float()
+    err = float((outs[True][0].float() - ref).norm() / ref.norm())
+    print("rel-L2 vs fp32 definition: %.2e" % err)
+    assert err < (6e-4 if E.act_dtype() == torch.float16 else 5e-3)
+
+
+def test_gn_in_rejected_where_the_kernel_cannot_apply_it():
+    lib = L.load()
+    # 320 output channels: three column blocks -> not offered, and an error through the raw ABI
+    assert lib.sdmi_conv3x3_gn_in_ok(1, 96, 96, 320, 320, 320) == 0
+    assert lib.sdmi_conv3x3_gn_in_ok(1, 24, 24, 128, 128, 128) == 0        # too few tiles for 128-row window tiles
+    H = E.act_dtype()
+    x = torch.zeros((1, 96 * 96, 320), dtype=H, device=DEV)
+    W = torch.nn.Parameter(torch.zeros((320, 320, 3, 3), device=DEV))
+    wp = E.packed_conv3x3(W)
+    out = torch.zeros((1, 96 * 96, 320), dtype=H, device=DEV)
+    ss = torch.zeros((1, 320, 2), dtype=torch.float32, device=DEV)
+    ext = L.EpilogueExt(gn_in=ss.data_ptr())
+    with pytest.raises(L.SdmiError, match="gn_in"):
+        L.call("sdmi_conv3x3_ex", x.data_ptr(), 320, 1, 96, 96, 320, wp.data_ptr(), 320, 96, 96, 1, 1, 1, 0, 0, 0, 0, 0,
+               out.data_ptr(), 320, L.F_SILU, 0, 0, E._stream(), C.addressof(ext))
+    with pytest.raises(L.SdmiError, match="SDMI_F_SILU"):
+        L.call("sdmi_conv3x3_ex", x.data_ptr(), 320, 1, 96, 96, 320, wp.data_ptr(), 320, 96, 96, 1, 1, 1, 0, 0, 0, 0, 0,
+               out.data_ptr(), 320, L.F_SILU, 0, 0, E._stream(), 0)
+
+
+def test_vae_decode_with_gn_in_conv_bit_identical():
+    from AutoencoderKL import AutoencoderKL
+    from stable_diffusion_amd.synth import fill_state_dict
+    vae = AutoencoderKL()
+    fill_state_dict(vae.state_dict(), seed=5, fast=True)
+    vae = vae.to(DEV).eval()
+    z = T(np.random.RandomState(3).randn(1, 4, 32, 32).astype(np.float32)).to(DEV)
+    saved = E.GN_IN_CONV
+    outs = {}
+    for mode in (False, True):
+        E.GN_IN_CONV = mode
+        try:
+            with torch.no_grad():
+                outs[mode] = vae.decode(z).clone()
+        finally:
+            E.GN_IN_CONV = saved
+    assert torch.equal(outs[True], outs[False])
