@@ -156,6 +156,20 @@ int64_t sdmi_gemm_ws_bytes(int m, int n, int k, int batch, int rows_per_sample, 
  *      from its reduce kernel but no rowstats); asking for statistics
  *      a launch cannot deliver is an error, never a silent skip. */
 #define SDMI_F_LNFOLD 512u
+/* GroupNorm(+SiLU) of the RESULT, written by the second pass of a split-K launch (sdmi_epilogue_ext.gn_out): the conv -> GroupNorm
+ * -> SiLU sequences of layers/ResBlock.py:67-73 on the 24x24 / 12x12 levels, where every conv splits K and its result is small.
+ * y[m][ldy] receives act(GroupNorm(out)); the raw result is still written to `out` when keep_raw != 0 (someone else reads it: the
+ * residual stream), else `out` is not touched.  Bit-identical to the plain call followed by sdmi_groupnorm. */
+typedef struct sdmi_gn_out {
+  void* y;
+  int ldy;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int groups;
+  uint32_t flags;   /* SDMI_F_SILU or 0 */
+  int keep_raw;
+} sdmi_gn_out;
 typedef struct sdmi_epilogue_ext {
   float* colstats;          /* out, or NULL */
   float* rowstats;          /* out, or NULL */
@@ -169,6 +183,7 @@ typedef struct sdmi_epilogue_ext {
                              * layers/ResBlock.py:65-67, :72-74 and AutoencoderKL.py:193-194 in ONE pass over x, bit-identical to
                              * sdmi_groupnorm_apply followed by the plain conv.  Only where one 128-column block covers all output
                              * channels: stride 1, pad 1, cout <= 128, cin % 64 == 0, h*w % 128 == 0; other shapes are an error. */
+  const sdmi_gn_out* gn_out; /* NULL, or the GroupNorm that follows (split-K launches with small results only: sdmi_conv3x3_gn_out_ok) */
 } sdmi_epilogue_ext;
 int sdmi_gemm_ex(const void* a, int lda, int64_t sa, const void* w, int ldw, int64_t sw, void* out, int ldc,
                  int64_t sc, int m, int n, int k, int batch, const float* bias, const float* rowbias,
@@ -180,6 +195,9 @@ int sdmi_conv3x3_ex(const void* x, int ldx, int n, int h, int w, int cin, const 
                     void* stream, const sdmi_epilogue_ext* ext);
 /* 1 when sdmi_conv3x3_ex can take sdmi_epilogue_ext.gn_in for this stride-1 pad-1 same-size conv (input row stride ldx), else 0 */
 int sdmi_conv3x3_gn_in_ok(int n, int h, int w, int cin, int cout, int ldx);
+/* 1 when this conv splits K and its result is small enough for sdmi_epilogue_ext.gn_out, else 0 (flags as for sdmi_conv3x3) */
+int sdmi_conv3x3_gn_out_ok(int n, int h, int w, int cin, int cout, int hout, int wout, int stride, int pad_t, int pad_l, uint32_t flags,
+                           int groups);
 /* parts of the statistics the calls above write for this problem: *row_parts (colstats) and *col_parts (rowstats); 0 where
  * the problem cannot emit them.  Either pointer may be NULL.  (upsample: SDMI_F_UPSAMPLE2X in flags) */
 int sdmi_gemm_stats_parts(int m, int n, int k, int batch, int rows_per_sample, uint32_t flags, int* row_parts, int* col_parts);

@@ -15,10 +15,16 @@ F_LNFOLD = 512
 F_WS_TICKETS = 1024
 
 
+class GnOut(C.Structure):
+    """sdmi_gn_out (include/sdmi.h)."""
+    _fields_ = [("y", C.c_void_p), ("ldy", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("groups", C.c_int),
+                ("flags", C.c_uint32), ("keep_raw", C.c_int)]
+
+
 class EpilogueExt(C.Structure):
     """sdmi_epilogue_ext (include/sdmi.h)."""
     _fields_ = [("colstats", C.c_void_p), ("rowstats", C.c_void_p), ("ln_rowstats", C.c_void_p), ("ln_u", C.c_void_p),
-                ("ln_parts", C.c_int), ("ln_eps", C.c_float), ("gn_in", C.c_void_p)]
+                ("ln_parts", C.c_int), ("ln_eps", C.c_float), ("gn_in", C.c_void_p), ("gn_out", C.POINTER(GnOut))]
 
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -50,6 +56,7 @@ PROTOTYPES = {
     "sdmi_gemm_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _u32]),
     "sdmi_gemm_ex": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp, _i64, _vp, _vp]),
     "sdmi_conv3x3_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp, _i64, _vp, _vp]),
+    "sdmi_conv3x3_gn_out_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u32, _i]),
     "sdmi_conv3x3_gn_in_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "sdmi_gemm_stats_parts": (_i, [_i, _i, _i, _i, _i, _u32, _vp, _vp]),
     "sdmi_conv3x3_stats_parts": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u32, _vp]),

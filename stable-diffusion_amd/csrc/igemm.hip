@@ -186,6 +186,132 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_stats_kernel(const Ig
 }
 
 
+// Split-K second pass fused with the GroupNorm(+SiLU) that follows the conv (sdmi_epilogue_ext.gn_out; verdict item 5): on the
+// 24x24 / 12x12 levels every conv is a split-K launch and the next kernel is a GroupNorm of its (small) result.  One
+// 1024-thread block owns one (sample, group): it sums the group's fp32 partials in split order, runs the epilogue (alpha, bias,
+// per-sample bias, residual), rounds to the storage type - the values igemm_splitk_reduce_kernel would have stored - keeps
+// them in registers, takes the exact two-pass statistics of gn_fused_kernel (csrc/norm.hip) from them and writes the
+// normalised tensor; the raw tensor is written too when someone else reads it (keep_raw).  Same summation orders, same
+// expressions as the reduce kernel followed by gn_fused_kernel: bit-identical to that pair (tested), one launch and one
+// round trip of the tensor less.
+struct GnOutParams {
+  u16* y; int ldy; const float* gamma; const float* beta; float eps; int groups; int silu; int keep_raw;
+};
+template <int DPT>
+__global__ __launch_bounds__(1024) void igemm_splitk_reduce_gn_kernel(const IgemmParams p, const GnOutParams go) {
+  __shared__ float s_red[16];
+  __shared__ float s_sc[160], s_sh[160];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int groups = go.groups, cpg = p.N / groups, hw = p.rows_per_sample;
+  int g, n;
+  {
+    const int bid = blockIdx.x;
+    if ((groups & 7) == 0) {  // blocks b and b + 8 share an XCD: neighbouring groups (they share 128-byte lines) on one XCD
+      const int gpx = groups >> 3, xcd = bid & 7, k = bid >> 3;
+      g = xcd * gpx + k % gpx;
+      n = k / gpx;
+    } else {
+      g = bid % groups;
+      n = bid / groups;
+    }
+  }
+  const int dpr = cpg >> 1;  // channel pairs per row of this group
+  const int total = hw * dpr;
+  const int qstep = 1024 / dpr, rstep = 1024 - qstep * dpr;
+  const long long per_split = (long long)p.M * p.npad;
+  const uint32_t fl = p.flags;
+  float2 acc[DPT];
+  int off[DPT];  // row * 4096 + pair index (hw <= 2^19, dpr <= 80)
+  {
+    int row = t / dpr, d = t - row * dpr;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const bool ok = k * 1024 + t < total;
+      off[k] = ok ? (row << 12) | d : -1;
+      d += rstep; row += qstep;
+      if (d >= dpr) { d -= dpr; ++row; }
+    }
+  }
+  const float* const zp = (const float*)g_zero16;
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) {
+    const long long m = (long long)n * hw + (off[k] >> 12);
+    acc[k] = *(const float2*)(off[k] >= 0 ? p.ws + m * p.npad + g * cpg + 2 * (off[k] & 4095) : zp);
+  }
+  for (int s = 1; s < p.splits; ++s) {
+    float2 b[DPT];
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const long long m = (long long)n * hw + (off[k] >> 12);
+      b[k] = *(const float2*)(off[k] >= 0 ? p.ws + s * per_split + m * p.npad + g * cpg + 2 * (off[k] & 4095) : zp);
+    }
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) { acc[k].x += b[k].x; acc[k].y += b[k].y; }
+  }
+  unsigned v[DPT];
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) {
+    const int row = off[k] >> 12, c0 = g * cpg + 2 * (off[k] & 4095);
+    const long long m = (long long)n * hw + row;
+    float y0 = acc[k].x * p.alpha, y1 = acc[k].y * p.alpha;
+    if (off[k] >= 0) {
+      if (fl & SDMI_F_BIAS) { y0 += p.bias[c0]; y1 += p.bias[c0 + 1]; }
+      if (fl & SDMI_F_ROWBIAS) { y0 += p.rowbias[(long long)n * p.ldrb + c0]; y1 += p.rowbias[(long long)n * p.ldrb + c0 + 1]; }
+      if (fl & SDMI_F_RESIDUAL) {
+        float r0, r1;
+        unpack2(*(const unsigned*)(p.res + m * p.ldr + c0), r0, r1);
+        y0 += r0; y1 += r1;
+      }
+      v[k] = pack2h(y0, y1);
+      if (go.keep_raw) *(unsigned*)((u16*)p.out + m * p.ldc + c0) = v[k];
+    } else {
+      v[k] = 0u;
+    }
+  }
+  // ---- gn_fused_kernel's statistics and apply, on the rounded values
+  float sm = 0.f;
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) { float a, b; unpack2(v[k], a, b); sm += a + b; }
+  sm = wave_sum(sm);
+  if (lane == 0) s_red[wv] = sm;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += s_red[w];
+  const float cnt = (float)hw * (float)cpg;
+  const float mean = tot / cnt;
+  __syncthreads();
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) {
+    float a, b; unpack2(v[k], a, b);
+    const float da = a - mean, db = b - mean;
+    ss += (off[k] >= 0) ? __builtin_fmaf(db, db, da * da) : 0.f;
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) s_red[wv] = ss;
+  __syncthreads();
+  float vtot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) vtot += s_red[w];
+  const float rstd = 1.0f / sqrtf(vtot / cnt + go.eps);
+  if (t < cpg) {
+    const float sc = go.gamma[g * cpg + t] * rstd;
+    s_sc[t] = sc;
+    s_sh[t] = __builtin_fmaf(-mean, sc, go.beta[g * cpg + t]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) {
+    const int row = off[k] >> 12, d = off[k] >= 0 ? off[k] & 4095 : 0;
+    float a, b; unpack2(v[k], a, b);
+    float oa = __builtin_fmaf(a, s_sc[2 * d], s_sh[2 * d]), ob = __builtin_fmaf(b, s_sc[2 * d + 1], s_sh[2 * d + 1]);
+    if (go.silu) { oa = silu_f(oa); ob = silu_f(ob); }
+    if (off[k] >= 0) *(unsigned*)(go.y + ((long long)n * hw + row) * go.ldy + g * cpg + 2 * d) = pack2h(oa, ob);
+  }
+}
+
+
 // ---- fast epilogue.  The MFMA layout leaves a lane with 4 channels of one row (8-byte pieces, a dependent bias /
 // residual load each).  Lanes l and l^16 hold neighbouring 4-channel pieces of the same row, so for every pair of
 // 16-column tiles one ds_swizzle exchange (no LDS memory, no barrier) leaves each lane with 8 consecutive channels:
@@ -1936,6 +2062,39 @@ static void launch_win2_gn(dim3 grid, int bytes, hipStream_t st, const IgemmPara
   else launch_win2_cs<128, 128, false, true>(grid, bytes, st, p);
 }
 
+// the second pass of a split-K launch: plain reduce, reduce + column statistics, or reduce + the GroupNorm that follows
+static bool gn_out_shape_ok(const IgemmParams& p, int batch, int groups) {
+  if (groups <= 0 || p.N % groups != 0) return false;
+  const int cpg = p.N / groups;
+  const long long dwords = (long long)p.rows_per_sample * (cpg / 2);
+  // the fused GroupNorm's own rule (csrc/norm.hip, sdmi_groupnorm): a (sample, group) slice must fit one block's registers
+  const bool small = dwords <= 12 * 1024 || (dwords <= 24 * 1024 && cpg >= 40);
+  return p.splits > 1 && batch == 1 && small && cpg % 2 == 0 && cpg <= 160 && p.N % 4 == 0 && p.rows_per_sample > 0 &&
+         p.M % p.rows_per_sample == 0 && p.rows_per_sample < (1 << 19) && (long long)(p.M / p.rows_per_sample) * groups <= 65535 &&
+         !(p.flags & (SDMI_F_GEGLU | SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE | SDMI_F_OUT_F32 | SDMI_F_LNFOLD));
+}
+static int launch_splitk_second_pass(const IgemmParams& p, int batch, hipStream_t st, float* split_colstats, const sdmi_gn_out* gn) {
+  record_mid_event(st);
+  if (gn) {
+    GnOutParams go;
+    go.y = (u16*)gn->y; go.ldy = gn->ldy; go.gamma = gn->gamma; go.beta = gn->beta; go.eps = gn->eps; go.groups = gn->groups;
+    go.silu = (gn->flags & SDMI_F_SILU) ? 1 : 0; go.keep_raw = gn->keep_raw ? 1 : 0;
+    const int cpg = p.N / gn->groups;
+    const int dpt = (int)(((long long)p.rows_per_sample * (cpg / 2) + 1023) / 1024);
+    const dim3 grid((unsigned)((p.M / p.rows_per_sample) * gn->groups));
+    if (dpt <= 6) hipLaunchKernelGGL(igemm_splitk_reduce_gn_kernel<6>, grid, dim3(1024), 0, st, p, go);
+    else if (dpt <= 12) hipLaunchKernelGGL(igemm_splitk_reduce_gn_kernel<12>, grid, dim3(1024), 0, st, p, go);
+    else hipLaunchKernelGGL(igemm_splitk_reduce_gn_kernel<24>, grid, dim3(1024), 0, st, p, go);
+    return sdmi_check_launch("split-K reduce + GroupNorm");
+  }
+  long long items = (long long)batch * p.M * (p.npad / 4);
+  long long rb = (items + 255) / 256;
+  if (rb > 4096) rb = 4096;
+  if (split_colstats) hipLaunchKernelGGL(igemm_splitk_reduce_stats_kernel, dim3((unsigned)((p.M / 32) * ((p.N + 31) / 32))), dim3(256), 0, st, p, split_colstats);
+  else hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
+  return sdmi_check_launch("split-K reduce");
+}
+
 template <bool CONV>
 static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, hipStream_t st, const sdmi_epilogue_ext* ext = nullptr) {
   p.ws = nullptr;
@@ -1960,6 +2119,16 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
     p.gn_ss = ext->gn_in;
   } else {
     SDMI_REQUIRE(!CONV || !(p.flags & SDMI_F_SILU), "conv3x3: SDMI_F_SILU without sdmi_epilogue_ext.gn_in");
+  }
+  const sdmi_gn_out* gn_out = ext ? ext->gn_out : nullptr;
+  if (gn_out) {
+    // the split-K reduce also writes the GroupNorm that follows: only for launches that split K, on results small enough for
+    // the one-block-per-(sample, group) kernel; anything else is an error (sdmi_*_gn_out_ok tells beforehand)
+    SDMI_REQUIRE(gn_out->y && gn_out->gamma && gn_out->beta && gn_out->ldy % 2 == 0 && gn_out->ldy >= p.N && ((uintptr_t)gn_out->y & 3) == 0 && gn_out->eps > 0.f,
+                 "%s: gn_out needs y, gamma, beta, an even ldy >= N and eps > 0", CONV ? "conv3x3" : "gemm");
+    SDMI_REQUIRE(gn_out_shape_ok(p, batch, gn_out->groups) && !(p.flags & SDMI_F_WS_TICKETS) && !ext->colstats && !ext->rowstats && p.ldc % 2 == 0,
+                 "%s: gn_out needs a split-K launch whose (sample, group) slices fit one block (M=%d N=%d rows/sample=%d splits=%d groups=%d), "
+                 "without colstats / rowstats / SDMI_F_WS_TICKETS", CONV ? "conv3x3" : "gemm", p.M, p.N, p.rows_per_sample, p.splits, gn_out->groups);
   }
   if (ext) {
     int rparts = 0, cparts = 0;
@@ -2048,16 +2217,10 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         else hipLaunchKernelGGL((conv_win_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);
       }
       sdmi_note_kernel("%s<%d, %d, %s%s>%s", v2 ? "conv_win2_kernel" : "conv_win_kernel", bm, bn, p.colstats ? "true" : "false", p.gn_ss ? ", true" : "",
-                       (p.splits > 1 && !p.ticket) ? (split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
+                       (p.splits > 1 && !p.ticket) ? (gn_out ? " + igemm_splitk_reduce_gn_kernel" : split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
       int rcw = sdmi_check_launch("conv3x3 (shared window)");
       if (rcw || p.splits < 2 || p.ticket) return rcw;
-      long long items = (long long)batch * p.M * (p.npad / 4);
-      long long rb = (items + 255) / 256;
-      if (rb > 4096) rb = 4096;
-      record_mid_event(st);
-      if (split_colstats) hipLaunchKernelGGL(igemm_splitk_reduce_stats_kernel, dim3((unsigned)((p.M / 32) * ((p.N + 31) / 32))), dim3(256), 0, st, p, split_colstats);
-      else hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
-      return sdmi_check_launch("split-K reduce");
+      return launch_splitk_second_pass(p, batch, st, split_colstats, gn_out);
     }
   }
   SDMI_REQUIRE(!p.gn_ss, "conv3x3: gn_in is only available on the shared-window kernel (SDMI_CONV_WIN=0 or a forced variant is set)");
@@ -2139,16 +2302,10 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
       break;
   }
   sdmi_note_kernel("igemm_kernel<%d, %d, %d, %d, %s, %d, %s>%s", bm, bn, tv.wm, tv.wn, CONV ? "true" : "false", tv.nstage,
-                   (p.flags & SDMI_F_GEGLU) ? "true" : "false", (p.splits > 1 && !p.ticket) ? (split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
+                   (p.flags & SDMI_F_GEGLU) ? "true" : "false", (p.splits > 1 && !p.ticket) ? (gn_out ? " + igemm_splitk_reduce_gn_kernel" : split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
   int rc = sdmi_check_launch(CONV ? "conv3x3" : "gemm");
   if (rc || p.splits < 2 || p.ticket) return rc;
-  long long items = (long long)batch * p.M * (p.npad / 4);
-  long long rb = (items + 255) / 256;
-  if (rb > 4096) rb = 4096;
-  record_mid_event(st);
-  if (split_colstats) hipLaunchKernelGGL(igemm_splitk_reduce_stats_kernel, dim3((unsigned)((p.M / 32) * ((p.N + 31) / 32))), dim3(256), 0, st, p, split_colstats);
-  else hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p, batch);
-  return sdmi_check_launch("split-K reduce");
+  return launch_splitk_second_pass(p, batch, st, split_colstats, gn_out);
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -2249,11 +2406,20 @@ extern "C" int sdmi_conv3x3_gn_in_ok(int n, int h, int w, int cin, int cout, int
   return gn_in_ok(p, vi, 1) ? 1 : 0;
 }
 
+extern "C" int sdmi_conv3x3_gn_out_ok(int n, int h, int w, int cin, int cout, int hout, int wout, int stride, int pad_t, int pad_l, uint32_t flags,
+                                      int groups) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || hout <= 0 || wout <= 0) return 0;
+  IgemmParams p;
+  conv_params(p, nullptr, cin, n, h, w, cin, nullptr, cout, hout, wout, stride, pad_t, pad_l, nullptr, nullptr, 0, nullptr, 0, nullptr, cout, flags);
+  (void)plan_igemm<true>(p, 1, true, (int64_t)1 << 62);
+  return gn_out_shape_ok(p, 1, groups) ? 1 : 0;
+}
+
 extern "C" int sdmi_conv3x3_ex(const void* x, int ldx, int n, int h, int w, int cin, const void* w_packed, int cout, int hout,
                                int wout, int stride, int pad_t, int pad_l, const float* bias, const float* rowbias, int ldrb,
                                const void* residual, int ldr, void* out, int ldc, uint32_t flags, void* ws, int64_t ws_bytes,
                                void* stream, const sdmi_epilogue_ext* ext) {
-  SDMI_REQUIRE(x && w_packed && out, "conv3x3: null pointer");
+  SDMI_REQUIRE(x && w_packed && (out || (ext && ext->gn_out && !ext->gn_out->keep_raw)), "conv3x3: null pointer");
   SDMI_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && hout > 0 && wout > 0, "conv3x3: bad shape");
   SDMI_REQUIRE(cin % 8 == 0 && ldx % 8 == 0 && ldx >= cin, "conv3x3: cin and ldx must be multiples of 8 (cin=%d ldx=%d)", cin, ldx);
   SDMI_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride %d", stride);

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const u16* __restrict__ 
   for (int k = 0; k < DPT; ++k) {
     float a, b; unpack2(v[k], a, b);
     const float da = a - mean, db = b - mean;
-    ss += (k * 1024 + t < total) ? da * da + db * db : 0.f;
+    ss += (k * 1024 + t < total) ? __builtin_fmaf(db, db, da * da) : 0.f;   // explicit: igemm_splitk_reduce_gn_kernel repeats it bit for bit
   }
   ss = wave_sum(ss);
   if (lane == 0) s_red[wv] = ss;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const u16* __restrict__ 
   if (t < cpg) {
     const float sc = gamma[g * cpg + t] * rstd;
     s_sc[t] = sc;
-    s_sh[t] = beta[g * cpg + t] - mean * sc;
+    s_sh[t] = __builtin_fmaf(-mean, sc, beta[g * cpg + t]);
   }
   __syncthreads();
   {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const u16* __restrict__ 
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
       float a, b; unpack2(v[k], a, b);
-      float oa = a * s_sc[2 * d] + s_sh[2 * d], ob = b * s_sc[2 * d + 1] + s_sh[2 * d + 1];
+      float oa = __builtin_fmaf(a, s_sc[2 * d], s_sh[2 * d]), ob = __builtin_fmaf(b, s_sc[2 * d + 1], s_sh[2 * d + 1]);
       if (silu) { oa = silu_f(oa); ob = silu_f(ob); }
       if (k * 1024 + t < total) *(unsigned*)(yb + (long long)row * ldy + 2 * d) = pack2h(oa, ob);
       d += rstep; row += qstep;

@@ -54,7 +54,8 @@ class ResBlock(nn.Module):
     def run(self, a, emb=None, ldrb=0, out=None):
         """emb: device pointer (int) or fp32 tensor holding emb_proj(SiLU(t_emb)) rows of stride ldrb, or None."""
         h = E.groupnorm(a, self.norm1.weight, self.norm1.bias, self.norm1.eps, silu=True, conv_cout=self.conv1.out_channels)
-        h = E.conv3x3(h, self.conv1.weight, self.conv1.bias, rowbias=emb, ldrb=ldrb)
+        h = E.conv3x3(h, self.conv1.weight, self.conv1.bias, rowbias=emb, ldrb=ldrb,
+                      gn_next=(self.norm2.weight, self.norm2.bias, self.norm2.eps, True), keep_raw=False)
         h = E.groupnorm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, silu=True, conv_cout=self.conv2.out_channels)
         if isinstance(self.skip_connection, nn.Conv2d):
             sk = self.skip_connection

@@ -40,13 +40,14 @@ class Act(object):
     stats: {column offset: (colstats tensor, row parts per sample, channels)} left by the kernels that produced column
     ranges of the buffer (shared by every view of it): per-channel sums for the GroupNorm that follows.
     rstats: (rowstats tensor, column parts) left by the GEMM that produced this view: per-row sums for a LayerNorm."""
-    __slots__ = ("buf", "n", "h", "w", "c", "off", "stats", "rstats", "gn")
+    __slots__ = ("buf", "n", "h", "w", "c", "off", "stats", "rstats", "gn", "normed")
 
     def __init__(self, buf, n, h, w, c, off=0, stats=None):
         self.buf, self.n, self.h, self.w, self.c, self.off = buf, n, h, w, c, off
         self.stats = {} if stats is None else stats
         self.rstats = None
         self.gn = None      # pending GroupNorm + SiLU: the (n, c, 2) scale/shift table the consuming conv applies itself
+        self.normed = None  # (key, Act): GroupNorm(+SiLU) of this tensor already written by its producer (conv3x3(gn_next=...))
 
     @property
     def hw(self):
@@ -54,15 +55,18 @@ class Act(object):
 
     @property
     def ld(self):
-        return self.buf.shape[-1]
+        return self.c if self.buf is None else self.buf.shape[-1]
 
     @property
     def ptr(self):
+        if self.buf is None:
+            raise L.SdmiError("this activation was never materialised: its producer wrote only the GroupNorm that follows it "
+                              "(conv3x3(..., gn_next=..., keep_raw=False))")
         return self.buf.data_ptr() + 2 * self.off
 
     @property
     def device(self):
-        return self.buf.device
+        return self.normed[1].device if self.buf is None else self.buf.device
 
     def cols(self, off, c):
         return Act(self.buf, self.n, self.h, self.w, c, self.off + off, self.stats)
@@ -239,6 +243,8 @@ RANGE_LOG = []
 def _audit(what, res):
     if not RANGE_AUDIT or not isinstance(res, Act) or act_dtype() != torch.float16:
         return
+    if res.buf is None:                 # only the GroupNorm of the result was written (conv3x3 gn_next, keep_raw=False)
+        res = res.normed[1]
     cnt = torch.zeros((1,), dtype=torch.int64, device=res.device)
     L.call("sdmi_count_saturated", res.ptr, res.ld, res.n * res.hw, res.c, cnt.data_ptr(), _stream())
     n = int(cnt.item())
@@ -252,6 +258,10 @@ USE_LNFOLD = os.environ.get("SDMI_LNFOLD", "1") == "1"         # LayerNorm folde
 # GroupNorm + SiLU applied by the consuming conv to its staged input (north-star item (b)); only convs whose one block column
 # covers every output channel qualify (the VAE's 128-channel level).  Default from the measurement in DESIGN.md section 5.
 GN_IN_CONV = os.environ.get("SDMI_GN_IN_CONV", "0") == "1"
+# the split-K reduce of a conv also writes the GroupNorm that follows it (24x24 / 12x12 levels).  Off: bit-identical and measured
+# SLOWER (captured step 7.81 -> 7.86 ms; per pair 40 -> 45 us at 24x24, 28.6 -> 29.8 at 12x12: one block per (sample, group) pulls
+# every split's slab of partials through 32 CUs, where the plain reduce kernel uses the whole chip; profiles/r03_gn_out_ab.txt)
+GN_OUT_FUSE = os.environ.get("SDMI_GN_OUT_FUSE", "0") == "1"
 
 
 def _gn_small(hw, c, groups):
@@ -273,12 +283,20 @@ def _stat_segments(a):
     return segs if pos == a.off + a.c else None
 
 
+def _gn_key(weight, bias, eps, silu, groups):
+    return (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, float(eps), bool(silu), int(groups))
+
+
 def groupnorm(a, weight, bias, eps, silu, groups=32, conv_cout=None):
     """GroupNorm(+SiLU): one fused launch when a (sample, group) slice fits a block; else, when the kernels that produced
     `a` left per-channel statistics (colstats), a fold of those + apply; else stats + apply (csrc/norm.hip).
     conv_cout: the result feeds ONLY a stride-1 pad-1 3x3 conv with that many output channels; where that conv can apply the
     normalisation to its own staged input (sdmi_epilogue_ext.gn_in, GN_IN_CONV) the apply pass is skipped: the returned view
     is the RAW tensor carrying the scale/shift table (Act.gn), which conv3x3 hands to the kernel."""
+    if a.normed is not None:
+        key, y = a.normed
+        if key == _gn_key(weight, bias, eps, silu, groups):
+            return y
     dev = a.device
     small = _gn_small(a.hw, a.c, groups)
     segs = _stat_segments(a) if (USE_COLSTATS and not small) else None
@@ -328,13 +346,18 @@ def layernorm(a, weight, bias, eps=1e-5):
 
 
 def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias=None, ldrb=0, residual=None,
-            out=None, out_nchw=False, out_u8_image=False):
-    """3x3 conv. pad = (left, right, top, bottom) as F.pad takes it. rowbias: fp32 tensor/ptr (per-sample channel add)."""
+            out=None, out_nchw=False, out_u8_image=False, gn_next=None, keep_raw=True):
+    """3x3 conv. pad = (left, right, top, bottom) as F.pad takes it. rowbias: fp32 tensor/ptr (per-sample channel add).
+    gn_next = (weight, bias, eps, silu[, groups]) of the GroupNorm that consumes the result: where the launch splits K and the
+    result is small (the 24x24 / 12x12 levels) the split-K reduce writes that GroupNorm too (sdmi_epilogue_ext.gn_out, GN_OUT_FUSE)
+    and the returned Act carries it (Act.normed; engine.groupnorm returns it).  keep_raw=False: nobody but that GroupNorm
+    reads the result, so the raw tensor is not written at all."""
     wp = packed_conv3x3(weight)
     cout, cin = weight.shape[0], weight.shape[1]
     if cin != a.c:
         raise L.SdmiError("conv3x3: input has %d channels, weight expects %d" % (a.c, cin))
     pl, pr, pt, pb = pad
+    gno = None
     if a.gn is not None and (stride != 1 or upsample or tuple(pad) != (1, 1, 1, 1)):
         raise L.SdmiError("conv3x3: the input carries a pending GroupNorm (Act.gn) that only a stride-1 pad-1 conv can apply")
     hin, win = (a.h * 2, a.w * 2) if upsample else (a.h, a.w)
@@ -369,12 +392,27 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
                                   ((a.n, cout, ho, wo), tuple(res.shape), res.dtype))
         optr, ldc = res.data_ptr(), 0
     else:
-        res = out if out is not None else new_act(a.n, ho, wo, cout, a.device)
-        _check_out(res, a.n, ho, wo, cout, "conv3x3")
-        optr, ldc = res.ptr, res.ld
+        gno = None
+        if gn_next is not None and GN_OUT_FUSE:
+            groups = gn_next[4] if len(gn_next) > 4 else 32
+            if L.load().sdmi_conv3x3_gn_out_ok(a.n, a.h, a.w, cin, cout, ho, wo, stride, pt, pl, flags, groups) == 1:
+                gy = new_act(a.n, ho, wo, cout, a.device)
+                gno = L.GnOut(y=gy.ptr, ldy=gy.ld, gamma=_f32c(gn_next[0], "gn weight").data_ptr(), beta=_f32c(gn_next[1], "gn bias").data_ptr(),
+                              eps=float(gn_next[2]), groups=groups, flags=L.F_SILU if gn_next[3] else 0, keep_raw=1 if (keep_raw or out is not None) else 0)
+        if gno is not None and not gno.keep_raw:
+            res = Act(None, a.n, ho, wo, cout)
+            optr, ldc = 0, cout
+        else:
+            res = out if out is not None else new_act(a.n, ho, wo, cout, a.device)
+            _check_out(res, a.n, ho, wo, cout, "conv3x3")
+            optr, ldc = res.ptr, res.ld
     ws, wsb = _workspace(a.device, L.load().sdmi_conv3x3_ws_bytes(a.n, cin, cout, ho, wo))
     ext = None
-    if USE_COLSTATS and isinstance(res, Act) and ho * wo >= 2304:
+    if isinstance(res, Act) and gno is not None:
+        res.stats.pop(res.off, None)
+        res.normed = (_gn_key(gn_next[0], gn_next[1], gn_next[2], gn_next[3], groups), gy)
+        ext = L.EpilogueExt(gn_out=ctypes.pointer(gno))
+    elif USE_COLSTATS and isinstance(res, Act) and ho * wo >= 2304:
         # leave per-channel statistics for the GroupNorm that follows (large tensors only: small ones use the fused kernel)
         rp = ctypes.c_int(0)
         L.call("sdmi_conv3x3_stats_parts", a.n, a.h, a.w, cin, cout, ho, wo, stride, pt, pl, flags, ctypes.addressof(rp))

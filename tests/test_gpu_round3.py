@@ -527,3 +527,91 @@ def test_vae_decode_with_gn_in_conv_bit_identical():
         finally:
             E.GN_IN_CONV = saved
     assert torch.equal(outs[True], outs[False])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Split-K reduce fused with the GroupNorm that follows (sdmi_epilogue_ext.gn_out, igemm_splitk_reduce_gn_kernel; review item 5):
+# bit-identical to reduce kernel + gn_fused_kernel, with and without the raw tensor, through a ResBlock and the whole UNet.
+@pytest.mark.parametrize("n,hh,cin,cout,keep,resid", [(1, 24, 1280, 1280, False, False), (2, 12, 1280, 1280, True, True),
+                                                       (1, 24, 640, 1280, True, False), (1, 12, 2560, 1280, False, False),
+                                                       (3, 6, 1280, 1280, True, True)])
+def test_splitk_reduce_writes_following_groupnorm_bit_identical(n, hh, cin, cout, keep, resid):
+    lib = L.load()
+    rs = np.random.RandomState(hh + cin + n)
+    H = E.act_dtype()
+    a = E.Act(T(rs.randn(n, hh * hh, cin).astype(np.float32)).to(DEV).to(H), n, hh, hh, cin)
+    W = torch.nn.Parameter(T((rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)).to(DEV))
+    B = torch.nn.Parameter(T(rs.randn(cout).astype(np.float32)).to(DEV))
+    emb = T(rs.randn(n, cout).astype(np.float32)).to(DEV)
+    gw = torch.nn.Parameter(T((1.0 + 0.3 * rs.randn(cout)).astype(np.float32)).to(DEV))
+    gb = torch.nn.Parameter(T((0.2 * rs.randn(cout)).astype(np.float32)).to(DEV))
+    res = E.Act(T(rs.randn(n, hh * hh, cout).astype(np.float32)).to(DEV).to(H), n, hh, hh, cout) if resid else None
+    assert lib.sdmi_conv3x3_gn_out_ok(n, hh, hh, cin, cout, hh, hh, 1, 1, 1, L.F_BIAS | L.F_ROWBIAS, 32) == 1
+    saved = E.GN_OUT_FUSE
+    got = {}
+    for mode in (False, True):
+        E.GN_OUT_FUSE = mode
+        try:
+            o = E.conv3x3(a, W, B, rowbias=emb, ldrb=cout, residual=res, gn_next=(gw, gb, 1e-5, True), keep_raw=keep)
+            kern = lib.sdmi_last_kernel().decode()
+            assert (o.normed is not None) == mode and kern.endswith("igemm_splitk_reduce_gn_kernel") == mode, kern
+            y = E.groupnorm(o, gw, gb, 1e-5, silu=True)
+            got[mode] = (y.buf.clone(), None if o.buf is None else o.buf.clone())
+        finally:
+            E.GN_OUT_FUSE = saved
+    torch.cuda.synchronize()
+    assert torch.equal(got[True][0].view(torch.int16), got[False][0].view(torch.int16)), \
+        "max diff %g" % float((got[True][0].float() - got[False][0].float()).abs().max())
+    if keep:
+        assert torch.equal(got[True][1].view(torch.int16), got[False][1].view(torch.int16))
+    else:
+        assert got[True][1] is None
+    # a GroupNorm with other parameters must not pick the stored result up
+    E.GN_OUT_FUSE = True
+    try:
+        o = E.conv3x3(a, W, B, rowbias=emb, ldrb=cout, residual=res, gn_next=(gw, gb, 1e-5, True), keep_raw=True)
+        gw2 = torch.nn.Parameter(gw.detach() * 2.0)
+        y2 = E.groupnorm(o, gw2, gb, 1e-5, silu=True)
+    finally:
+        E.GN_OUT_FUSE = saved
+    assert not torch.equal(y2.buf, got[True][0])
+
+
+def test_gn_out_rejected_where_the_launch_does_not_split():
+    lib = L.load()
+    assert lib.sdmi_conv3x3_gn_out_ok(1, 96, 96, 320, 320, 96, 96, 1, 1, 1, 0, 32) == 0
+    H = E.act_dtype()
+    x = torch.zeros((1, 96 * 96, 320), dtype=H, device=DEV)
+    W = torch.nn.Parameter(torch.zeros((320, 320, 3, 3), device=DEV))
+    wp = E.packed_conv3x3(W)
+    out = torch.zeros((1, 96 * 96, 320), dtype=H, device=DEV)
+    y = torch.zeros((1, 96 * 96, 320), dtype=H, device=DEV)
+    g = torch.ones((320,), device=DEV)
+    go = L.GnOut(y=y.data_ptr(), ldy=320, gamma=g.data_ptr(), beta=g.data_ptr(), eps=1e-5, groups=32, flags=L.F_SILU, keep_raw=1)
+    ext = L.EpilogueExt(gn_out=C.pointer(go))
+    ws = torch.empty((1 << 22,), dtype=torch.float32, device=DEV)
+    with pytest.raises(L.SdmiError, match="gn_out"):
+        L.call("sdmi_conv3x3_ex", x.data_ptr(), 320, 1, 96, 96, 320, wp.data_ptr(), 320, 96, 96, 1, 1, 1, 0, 0, 0, 0, 0,
+               out.data_ptr(), 320, 0, ws.data_ptr(), ws.numel() * 4, E._stream(), C.addressof(ext))
+
+
+def test_unet_forward_with_reduce_gn_fusion_bit_identical():
+    from Unet import Unet
+    net = Unet()
+    fill_state_dict(net.state_dict(), seed=2, fast=True)
+    net = net.to(DEV).eval()
+    rs = np.random.RandomState(9)
+    x = T(rs.randn(2, 9, 96, 96).astype(np.float32)).to(DEV)
+    t = torch.tensor([500, 500], device=DEV)
+    ctx = T(rs.randn(2, 77, 1024).astype(np.float32)).to(DEV)
+    saved = E.GN_OUT_FUSE
+    outs = {}
+    for mode in (False, True):
+        E.GN_OUT_FUSE = mode
+        try:
+            with torch.no_grad():
+                outs[mode] = net(x, t, ctx).clone()
+        finally:
+            E.GN_OUT_FUSE = saved
+    assert torch.isfinite(outs[True]).all()
+    assert torch.equal(outs[True], outs[False])
