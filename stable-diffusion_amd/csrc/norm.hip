@@ -308,9 +308,11 @@ extern "C" int sdmi_groupnorm_apply(const void* x, int ldx, const float* scale_s
   const int lsh = gn_lpr_shift(c);
   const int rpp = 64 >> lsh;
   // 2 passes per wave, both in flight (8*rpp rows per block): many small blocks keep enough bytes in flight per CU;
-  // very large tensors get longer blocks (<= 8192 per sample)
+  // very large tensors get longer blocks (<= 32768 per sample; round 3: the cap was 8192, and the 768x768 levels of the VAE ran
+  // 96-row blocks at 4.9 TB/s where 32-row blocks reach 5.4 - profiles/r03_gn_apply_bw.txt, option gn_apply_rows)
   int rpb = 8 * rpp;
-  if ((hw + rpb - 1) / rpb > 8192) rpb = ((hw + 8191) / 8192 + 8 * rpp - 1) / (8 * rpp) * (8 * rpp);
+  if ((hw + rpb - 1) / rpb > 32768) rpb = ((hw + 32767) / 32768 + 8 * rpp - 1) / (8 * rpp) * (8 * rpp);
+  if (sdmi_opt(OPT_gn_apply_rows) > 0) rpb = sdmi_opt(OPT_gn_apply_rows) * 8 * rpp;
   dim3 grid((hw + rpb - 1) / rpb, n), block(256);
   const int ns = (c / 8 + 63) / 64;
   const int silu = (flags & SDMI_F_SILU) ? 1 : 0;
