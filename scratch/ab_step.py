@@ -19,7 +19,7 @@ t = torch.full((2 * B,), 501, dtype=torch.long, device=dev)
 uncond, cond = torch.randn(B, 77, 1024, device=dev), torch.randn(B, 77, 1024, device=dev)
 te = unet.precompute_time_embedding(t)
 
-OPTION_DEFAULTS = {"conv_plan_r2": 0, "attn_pp": 0, "conv_win_256": 0, "attn_variant": 0, "gemm_small_m_tile": 1, "conv_nmajor_by_rows": 0, "splitk_target": 0, "splitk_max_tiles": 0, "attn_x2_min_nq": 0, "splitk_min_kt_conv": 0, "splitk_min_kt_gemm": 0, "bm128_min": 0, "gemm_t2_min_blocks": 0, "split_colstats_off": 0, "gemm_persist": 0, "conv_win_v1": 0, "gemm_buf_off": 0}
+OPTION_DEFAULTS = {"conv_plan_r2": 0, "attn_pp": 0, "conv_win_256": 0, "attn_variant": 0, "gemm_small_m_tile": 1, "conv_nmajor_by_rows": 0, "splitk_target": 0, "splitk_max_tiles": 0, "attn_x2_min_nq": 0, "splitk_min_kt_conv": 0, "splitk_min_kt_gemm": 0, "bm128_min": 0, "gemm_t2_min_blocks": 0, "split_colstats_off": 0, "gemm_persist": 0, "conv_win_v1": 0, "gemm_buf_off": 0, "conv_win_ups_off": 0, "gn_apply_rows": 0}
 def apply(cfg):
     for k, v in OPTION_DEFAULTS.items():        # options are process-wide: every configuration starts from the defaults
         lib.sdmi_set_option(k.encode(), v)

@@ -58,6 +58,7 @@ void sdmi_note_kernel(const char* fmt, ...);  // records the kernel variant the 
   X(gemm_astat, 0, "1: A-stationary GEMM kernel (igemm_astat_kernel) for K <= 384 wherever it can run the problem (measured slower)")           \
   X(conv_plan_r2, 0, "1: split-K / tile rules of the convs as in round 2 (A/B switch for the round-3 rule changes)")                              \
   X(conv_win_v1, 0, "1: shared-window convs on the round-2 kernel (global_load_lds + per-lane pointers), A/B switch")                           \
+  X(conv_win_ups_off, 0, "1: nearest-2x upsample convs on the generic gather kernel instead of the shared-window variant, A/B switch")        \
   X(gn_apply_rows, 0, "> 0: rows per block of gn_apply_kernel in units of its 8-pass step (experiment)")
 enum SdmiOpt {
 #define SDMI_OPT_ENUM(name, def, doc) OPT_##name,

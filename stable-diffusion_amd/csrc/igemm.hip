@@ -1545,8 +1545,14 @@ __device__ __forceinline__ int lds_off_w(int row, int chunk) { return row * BK +
 // (fma, silu_f, saturating pack): the LDS holds the same bits the unfused pair would have staged, so the result is
 // bit-identical to sdmi_groupnorm_apply + this kernel.  One column block only (Cout <= BN, host): a second column block
 // would transform the same windows again.
-template <int BM, int BN, bool CS, bool GNA = false>
+// UPS (round 3): the nearest-2x upsample convs (layers/ResBlock.py:17-19) on the same kernel.  The window holds pixels of the
+// VIRTUAL upsampled image (2H x 2W); only the staging address changes - window row r for kernel row ky comes from source pixel
+// ((y + ky - 1) >> 1, x >> 1), a per-lane offset per ky computed once (the ky shift is no longer one scalar: it depends on the
+// parity of y), K position = the chunk's scalar offset.  Fragment reads, K order, epilogue: unchanged, so the same bits as the
+// generic kernel's gather loader with a third of its activation bytes staged.
+template <int BM, int BN, bool CS, bool GNA = false, bool UPS = false>
 __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_win2_kernel(const IgemmParams p) {
+  static_assert(!(GNA && UPS), "gn_in is not built for the upsample variant");
   constexpr int TM = BM / 2, TN = BN / 2, MT = TM / 16, NT = TN / 16;
   constexpr int WROWS = BM + 8;           // staged window rows: BM + 2 are read; whole 8-row DMA instructions
   constexpr int WBUF = (WROWS + 1) * BK;  // elements per window buffer, + one row of zeros
@@ -1558,7 +1564,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int brow = (p.nmajor ? bid % tiles_m : bid / tiles_n) * BM, bcol = (p.nmajor ? bid / tiles_m : bid % tiles_n) * BN;
-  const int hw = p.H * p.W;
+  const int VH = UPS ? 2 * p.H : p.H, VW = UPS ? 2 * p.W : p.W;  // the image the 3x3 taps walk (upsampled: virtual)
+  const int hw = VH * VW;
 
   if (t < 16) *(u32x4*)(smem + (t >> 3) * WBUF + WROWS * BK + (t & 7) * 8) = u32x4{0u, 0u, 0u, 0u};  // the zero rows
 
@@ -1569,18 +1576,27 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
   // window: descriptor base = pixel (brow - 1 - W), the first pixel a kernel row 0 read of window row 0 touches; window row r
   // for kernel row ky then sits at ((r + ky W) lda + chunk) elements.  The base may lie in front of the tensor: lanes whose
   // pixel does not exist are masked (offset DMA_OOB), never fetched.
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + ((long long)brow - 1 - p.W) * p.lda), 0, DMA_OOB, 0x00020000);
+  // (UPS: the descriptor starts at the tensor and the per-lane offsets are absolute: the host keeps the tensor below 2 GB)
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(UPS ? p.a : p.a + ((long long)brow - 1 - p.W) * p.lda), 0, DMA_OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)bcol * p.ldw), 0, DMA_OOB, 0x00020000);
   unsigned w_voff[PW];
-  int w_mask[PW];  // bit ky: window row readable for kernel row ky
+  int w_mask[PW];  // bit ky: window row readable for kernel row ky.  UPS: bit 4 / bits 5-6 = source rows to add for ky = 1 / 2
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
     const int r = r0 + 32 * i, q = brow - 1 + r;  // window row r holds pixel q (flat N*H*W index)
     const bool ok = r < BM + 2 && q >= 0 && q < p.M;  // rows BM + 2 ... of the last 8-row DMA group are never read: not fetched
     const int qc = ok ? q : 0;
-    const int img = qc / hw, y = (qc - img * hw) / p.W;
-    w_mask[i] = ok ? ((y >= 1 ? 1 : 0) | 2 | (y <= p.H - 2 ? 4 : 0)) : 0;
-    w_voff[i] = (unsigned)((r * p.lda + lchunk * 8) * 2);
+    const int img = qc / hw, y = (qc - img * hw) / VW;
+    w_mask[i] = ok ? ((y >= 1 ? 1 : 0) | 2 | (y <= VH - 2 ? 4 : 0)) : 0;
+    if constexpr (UPS) {
+      const int x = qc - img * hw - y * VW;
+      const int src0 = img * (p.H * p.W) + (x >> 1);  // + source row * W
+      const int ym = y >= 1 ? y - 1 : 0, yp = y <= VH - 2 ? y + 1 : y;
+      w_voff[i] = (unsigned)(((src0 + (ym >> 1) * p.W) * p.lda + lchunk * 8) * 2);  // kernel row 0; rows 1 / 2 lie 0 - 2 source rows below
+      w_mask[i] |= (((y >> 1) - (ym >> 1)) << 4) | (((yp >> 1) - (ym >> 1)) << 5);
+    } else {
+      w_voff[i] = (unsigned)((r * p.lda + lchunk * 8) * 2);
+    }
   }
   unsigned b_voff[PB];
 #pragma unroll
@@ -1597,10 +1613,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
     const int i = wr * TM + mi * 16 + l15, pix = brow + i;
     const bool pv = pix < p.M;
     const int pc = pv ? pix : 0;
-    const int x = (pc % hw) % p.W;
+    const int x = (pc % hw) % VW;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const bool valid = pv && x + kx - 1 >= 0 && x + kx - 1 < p.W;
+      const bool valid = pv && x + kx - 1 >= 0 && x + kx - 1 < VW;
       aoff[mi][kx] = valid ? lds_off_w(i + kx, lq) : WROWS * BK + lq * 8;
     }
   }
@@ -1614,21 +1630,22 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
   int w_cb = s_cb, w_ky = s_tap / 3;                                        // next window to stage
   const int row_bytes = p.W * p.lda * 2;                                    // one image row of the input
   // GNA: this thread's 8 channels of the chunk whose windows are being transformed, and the next window to transform
-  [[maybe_unused]] float gsc[8], gsh[8];
-  [[maybe_unused]] const float* gn_tab = nullptr;
-  [[maybe_unused]] int g_ky = w_ky;
-  if constexpr (GNA) gn_tab = p.gn_ss + ((long long)(brow / hw) * p.Cin + lchunk * 8) * 2;
-#define WIN2_GN_LOAD(CB)                                                                                  \
-  if constexpr (GNA) {                                                                                    \
-    const f32x4* sp = (const f32x4*)(gn_tab + (CB) * (BK * 2));                                           \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
-      const f32x4 v = sp[e];                                                                              \
-      gsc[2 * e] = v[0]; gsh[2 * e] = v[1]; gsc[2 * e + 1] = v[2]; gsh[2 * e + 1] = v[3];                 \
-    }                                                                                                     \
-  }
+  // (the sample's whole (scale, shift) table sits in the LDS behind the weight ring - Cin * 8 bytes, copied once: 16 registers
+  // per thread held across the K loop made the kernel spill)
+  [[maybe_unused]] int g_ky = w_ky, g_cb = w_cb;
+  [[maybe_unused]] float* const gtab = (float*)(bring + 2 * BSLOT);
+#define WIN2_GN_LOAD(CB)
 #define WIN2_GN_APPLY(WBI)                                                                                \
   if constexpr (GNA) {                                                                                    \
     const int kbit = 1 << g_ky;                                                                           \
+    float gsc[8], gsh[8];                                                                                 \
+    {                                                                                                     \
+      const f32x4* sp = (const f32x4*)(gtab + (g_cb * BK + lchunk * 8) * 2);                              \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                     \
+        const f32x4 v = sp[e];                                                                            \
+        gsc[2 * e] = v[0]; gsh[2 * e] = v[1]; gsc[2 * e + 1] = v[2]; gsh[2 * e + 1] = v[3];               \
+      }                                                                                                   \
+    }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < PW; ++i) {                                                      \
       if (wave_row0 + 32 * i < WROWS && (w_mask[i] & kbit)) {                                             \
         uint4* q = (uint4*)(smem + (WBI) * WBUF + (r0 + 32 * i) * BK + (t & 7) * 8);                      \
@@ -1638,16 +1655,19 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
         *q = pack8(f);                                                                                    \
       }                                                                                                   \
     }                                                                                                     \
-    if (++g_ky == 3) g_ky = 0;                                                                            \
+    if (++g_ky == 3) { g_ky = 0; ++g_cb; }                                                                \
   }
 
 #define WIN2_STAGE_W(WBI)                                                                                 \
   {                                                                                                       \
-    const int soff = w_ky * row_bytes + w_cb * (BK * 2);                                                  \
+    const int soff = (UPS ? 0 : w_ky * row_bytes) + w_cb * (BK * 2);                                      \
     const int kbit = 1 << w_ky;                                                                           \
+    [[maybe_unused]] const int ups_sh = w_ky == 1 ? 4 : 5, ups_and = w_ky == 0 ? 0 : (w_ky == 1 ? 1 : 3); \
     _Pragma("unroll") for (int i = 0; i < PW; ++i) {                                                      \
       if (wave_row0 + 32 * i < WROWS) {                                                                   \
-        const unsigned vo = (w_mask[i] & kbit) ? w_voff[i] : DMA_OOB;                                     \
+        unsigned vsel = w_voff[i];                                                                        \
+        if constexpr (UPS) vsel += (unsigned)(((w_mask[i] >> ups_sh) & ups_and) * row_bytes);             \
+        const unsigned vo = (w_mask[i] & kbit) ? vsel : DMA_OOB;                                          \
         dma_buf16(rsrcA, vo, soff, lds0 + ((WBI) * WBUF + (wave_row0 + 32 * i) * BK) * 2);                \
       }                                                                                                   \
     }                                                                                                     \
@@ -1693,7 +1713,11 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : (BN == 64 ? 3 : 2)) void conv_
   WIN2_STAGE_B(0);
   WIN2_STAGE_B(1);
   if constexpr (GNA) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's own pieces have landed
+    // the table copy rides behind the first DMAs; its load is the youngest in the queue, so the wait it needs is vmcnt(0)
+    const float* src = p.gn_ss + (long long)(brow / hw) * p.Cin * 2;
+    for (int i = t; i < p.Cin / 2; i += 256) *(f32x4*)(gtab + 4 * i) = *(const f32x4*)(src + 4 * i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // and this thread's own window pieces have landed
+    __syncthreads();
     WIN2_GN_APPLY(0);
   }
   WIN2_WAIT();
@@ -1944,12 +1968,17 @@ static int variant_blocks_per_cu(const TileVariant& tv, bool ln) {
 // gives every CU a block wins; SDMI_IGEMM_TILE=<index into kVariants> forces one (experiments).
 // what the shared-window conv kernels need (stride 1, pad 1, same size, no upsampling; v2: whole 64-channel chunks, 32-bit
 // panel offsets)
-static bool conv_window_shape(const IgemmParams& p, int batch) {
-  return p.stride == 1 && !p.ups && p.pad_t == 1 && p.pad_l == 1 && p.Ho == p.H && p.Wo == p.W && batch == 1;
-}
 static bool conv_win2_ok(const IgemmParams& p, int bm) {
+  if (p.ups)  // absolute per-lane offsets from the start of the tensor (conv_win2_kernel UPS)
+    return !sdmi_opt(OPT_conv_win_v1) && !sdmi_opt(OPT_conv_win_ups_off) && bm == 128 && p.Cin % 64 == 0 && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
+           (long long)(p.M / 4) * p.lda * 2 + 2 * p.Cin < (1ll << 31);
   return !sdmi_opt(OPT_conv_win_v1) && p.Cin % 64 == 0 && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
          ((long long)(bm + 16) + 2 * p.W) * p.lda * 2 + 2 * p.Cin < (1ll << 31);
+}
+static bool conv_window_shape(const IgemmParams& p, int batch) {
+  if (p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || batch != 1) return false;
+  if (p.ups) return p.Ho == 2 * p.H && p.Wo == 2 * p.W && conv_win2_ok(p, 128);  // only the round-3 kernel has the upsample variant
+  return p.Ho == p.H && p.Wo == p.W;
 }
 static int choose_variant(const IgemmParams& p, int batch, bool conv) {
   static int forced = -2;
@@ -2035,13 +2064,13 @@ static void stats_parts_of(const IgemmParams& p, int batch, int vi, int* row_par
 static bool gn_in_ok(const IgemmParams& p, int vi, int batch) {
   static int win_env = -1;
   if (win_env < 0) { const char* e = getenv("SDMI_CONV_WIN"); win_env = (e && e[0] == '0') ? 0 : 1; }
-  return vi == 1 && p.N <= 128 && p.splits == 1 && batch == 1 && p.rows_per_sample % 128 == 0 && conv_window_shape(p, batch) &&
+  return vi == 1 && !p.ups && p.Cin <= 1024 && p.N <= 128 && p.splits == 1 && batch == 1 && p.rows_per_sample % 128 == 0 && conv_window_shape(p, batch) &&
          conv_win2_ok(p, 128) && (g_force_window >= 0 ? g_force_window : win_env) != 0;
 }
 // conv_win2_kernel launch; > 64 KB of dynamic LDS allowed once per device
-template <int BM, int BN, bool CS, bool GNA = false>
+template <int BM, int BN, bool CS, bool GNA = false, bool UPS = false>
 static void launch_win2_cs(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
-  auto kfn = conv_win2_kernel<BM, BN, CS, GNA>;
+  auto kfn = conv_win2_kernel<BM, BN, CS, GNA, UPS>;
   static unsigned long long attr_done = 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -2053,11 +2082,19 @@ static void launch_win2_cs(dim3 grid, int bytes, hipStream_t st, const IgemmPara
 }
 template <int BM, int BN>
 static void launch_win2(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
+  if constexpr (BM == 128) {
+    if (p.ups) {
+      if (p.colstats) launch_win2_cs<BM, BN, true, false, true>(grid, bytes, st, p);
+      else launch_win2_cs<BM, BN, false, false, true>(grid, bytes, st, p);
+      return;
+    }
+  }
   if (p.colstats) launch_win2_cs<BM, BN, true>(grid, bytes, st, p);
   else launch_win2_cs<BM, BN, false>(grid, bytes, st, p);
 }
 // GroupNorm + SiLU of the input applied to the staged windows (128 x 128 tiles, one column block)
 static void launch_win2_gn(dim3 grid, int bytes, hipStream_t st, const IgemmParams& p) {
+  bytes += 8192;  // the (scale, shift) table of one sample: Cin * 8 bytes, Cin <= 1024 (gn_in_ok); 75 KB: still two blocks per CU
   if (p.colstats) launch_win2_cs<128, 128, true, true>(grid, bytes, st, p);
   else launch_win2_cs<128, 128, false, true>(grid, bytes, st, p);
 }
@@ -2216,7 +2253,7 @@ static int launch_igemm(IgemmParams& p, int batch, void* ws, int64_t ws_bytes, h
         if (p.colstats) hipLaunchKernelGGL((conv_win_kernel<128, 64, true>), grid, dim3(256), wbytes64, st, p);
         else hipLaunchKernelGGL((conv_win_kernel<128, 64, false>), grid, dim3(256), wbytes64, st, p);
       }
-      sdmi_note_kernel("%s<%d, %d, %s%s>%s", v2 ? "conv_win2_kernel" : "conv_win_kernel", bm, bn, p.colstats ? "true" : "false", p.gn_ss ? ", true" : "",
+      sdmi_note_kernel("%s<%d, %d, %s%s>%s", v2 ? "conv_win2_kernel" : "conv_win_kernel", bm, bn, p.colstats ? "true" : "false", p.gn_ss ? ", true" : (p.ups ? ", false, true" : ""),
                        (p.splits > 1 && !p.ticket) ? (gn_out ? " + igemm_splitk_reduce_gn_kernel" : split_colstats ? " + igemm_splitk_reduce_stats_kernel" : " + igemm_splitk_reduce_kernel") : "");
       int rcw = sdmi_check_launch("conv3x3 (shared window)");
       if (rcw || p.splits < 2 || p.ticket) return rcw;

@@ -615,3 +615,41 @@ def test_unet_forward_with_reduce_gn_fusion_bit_identical():
             E.GN_OUT_FUSE = saved
     assert torch.isfinite(outs[True]).all()
     assert torch.equal(outs[True], outs[False])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Nearest-2x upsample convs on the shared-window kernel (conv_win2_kernel<..., UPS>): the bits of the generic gather kernel,
+# with colstats, split-K, several samples, odd source sizes.
+@pytest.mark.parametrize("n,hh,ww,c,cout", [(1, 48, 48, 640, 640), (2, 24, 24, 1280, 1280), (1, 12, 12, 1280, 1280),
+                                             (1, 96, 96, 128, 256), (3, 20, 12, 64, 64), (1, 33, 17, 192, 128)])
+def test_upsample_conv_on_window_kernel_bit_identical(n, hh, ww, c, cout):
+    lib = L.load()
+    rs = np.random.RandomState(hh + c)
+    H = E.act_dtype()
+    a = E.Act(T(rs.randn(n, hh * ww, c).astype(np.float32)).to(DEV).to(H), n, hh, ww, c)
+    W = torch.nn.Parameter(T((rs.randn(cout, c, 3, 3) / np.sqrt(9 * c)).astype(np.float32)).to(DEV))
+    B = torch.nn.Parameter(T(rs.randn(cout).astype(np.float32)).to(DEV))
+    got, kern, stats = {}, {}, {}
+    for off in (1, 0):
+        assert lib.sdmi_set_option(b"conv_win_ups_off", off) == 0
+        try:
+            o = E.conv3x3(a, W, B, upsample=True)
+            kern[off] = lib.sdmi_last_kernel().decode()
+            got[off] = o.buf.clone()
+            stats[off] = o.stats[o.off][0].clone() if o.off in o.stats else None
+        finally:
+            lib.sdmi_set_option(b"conv_win_ups_off", 0)
+    torch.cuda.synchronize()
+    print(kern)
+    assert kern[1].startswith("igemm_kernel")
+    if kern[0].startswith("conv_win2_kernel"):
+        assert ", false, true>" in kern[0]
+    assert torch.equal(got[0].view(torch.int16), got[1].view(torch.int16)), "max diff %g" % float((got[0].float() - got[1].float()).abs().max())
+    if stats[1] is not None:
+        assert stats[0] is not None and torch.equal(stats[0], stats[1])
+    with torch.no_grad():
+        import torch.nn.functional as F
+        xf = a.buf.float().reshape(n, hh, ww, c).permute(0, 3, 1, 2)
+        ref = F.conv2d(F.pad(F.interpolate(xf, scale_factor=2.0, mode="nearest"), (1, 1, 1, 1)), W, B).permute(0, 2, 3, 1).reshape(n, 4 * hh * ww, cout)
+    err = float((got[0].float() - ref).norm() / ref.norm())
+    assert err < 6e-4 * _tol(), err
