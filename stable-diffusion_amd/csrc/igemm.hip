@@ -2104,8 +2104,9 @@ static bool gn_out_shape_ok(const IgemmParams& p, int batch, int groups) {
   if (groups <= 0 || p.N % groups != 0) return false;
   const int cpg = p.N / groups;
   const long long dwords = (long long)p.rows_per_sample * (cpg / 2);
-  // the fused GroupNorm's own rule (csrc/norm.hip, sdmi_groupnorm): a (sample, group) slice must fit one block's registers
-  const bool small = dwords <= 12 * 1024 || (dwords <= 24 * 1024 && cpg >= 40);
+  // a (sample, group) slice must fit one block's registers next to the fp32 sums of its partials: 12 channel pairs per thread
+  // (24 pairs - the largest slices sdmi_groupnorm's fused kernel takes - spill here; such results keep the two kernels)
+  const bool small = dwords <= 12 * 1024;
   return p.splits > 1 && batch == 1 && small && cpg % 2 == 0 && cpg <= 160 && p.N % 4 == 0 && p.rows_per_sample > 0 &&
          p.M % p.rows_per_sample == 0 && p.rows_per_sample < (1 << 19) && (long long)(p.M / p.rows_per_sample) * groups <= 65535 &&
          !(p.flags & (SDMI_F_GEGLU | SDMI_F_OUT_NCHW_F32 | SDMI_F_OUT_U8_IMAGE | SDMI_F_OUT_F32 | SDMI_F_LNFOLD));
@@ -2120,8 +2121,7 @@ static int launch_splitk_second_pass(const IgemmParams& p, int batch, hipStream_
     const int dpt = (int)(((long long)p.rows_per_sample * (cpg / 2) + 1023) / 1024);
     const dim3 grid((unsigned)((p.M / p.rows_per_sample) * gn->groups));
     if (dpt <= 6) hipLaunchKernelGGL(igemm_splitk_reduce_gn_kernel<6>, grid, dim3(1024), 0, st, p, go);
-    else if (dpt <= 12) hipLaunchKernelGGL(igemm_splitk_reduce_gn_kernel<12>, grid, dim3(1024), 0, st, p, go);
-    else hipLaunchKernelGGL(igemm_splitk_reduce_gn_kernel<24>, grid, dim3(1024), 0, st, p, go);
+    else hipLaunchKernelGGL(igemm_splitk_reduce_gn_kernel<12>, grid, dim3(1024), 0, st, p, go);
     return sdmi_check_launch("split-K reduce + GroupNorm");
   }
   long long items = (long long)batch * p.M * (p.npad / 4);
