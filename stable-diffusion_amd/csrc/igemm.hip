@@ -55,16 +55,26 @@ constexpr int BK = 64;  // K elements per pipeline stage (128-byte tile rows)
 // element offset of 16-byte chunk `chunk` (0..7) of tile row `row`; the XOR keeps the 16 lanes of a ds_read_b128 lane
 // group on 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3); }
-// exact (erf) GELU of the reference's GEGLU (layers/SpatialTransformer.py:37-47, F.gelu).  erf by Abramowitz & Stegun 7.1.26
-// (|error| <= 1.5e-7 absolute, on erfc for the negative side so small outputs keep their sign and scale): 14 vector
-// instructions instead of the library erff's 34 - the GEGLU GEMMs of the 96x96 level have K = 320, five K-tiles per
-// 128 x 128 tile, and their epilogue (32 GELUs per thread) cost more issue time than their MFMAs.
+// exact (erf) GELU of the reference's GEGLU (layers/SpatialTransformer.py:37-47, F.gelu):
+//   gelu(g) = max(g, 0) - |g| h(|g| / sqrt 2),   h(z) = erfc(z) / 2 = 2^p(z)
+// with p a degree-8 polynomial fit of log2(erfc(z) / 2) on [0, 4] (weighted for the absolute error of erfc; negative leading
+// coefficient, so p -> -inf and h -> 0 beyond the fit range: no clamp).  One transcendental and 11 plain instructions per
+// GELU - round 2's Abramowitz-Stegun 7.1.26 form took two transcendentals and 14 (the library erff 34): the GEGLU GEMMs of the
+// 96x96 level have K = 320, five K-tiles per 128 x 128 tile, and their 32 GELUs per thread cost more issue time than their
+// MFMAs.  |error| <= 2.7e-7 for |g| <= 12 evaluated in fp32 (A-S: 2.1e-7), exact limits g and -0 for large |g|; small negative
+// outputs keep their sign (the product -|g| h, never a difference of near-equal numbers).
 __device__ __forceinline__ float gelu_erf(float g) {
   const float z = fabsf(g) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float half_erfc = 0.5f * poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);  // (1 - erf|z|) / 2
-  return g >= 0.f ? g * (1.0f - half_erfc) : g * half_erfc;
+  float p = -4.060196594e-05f;
+  p = __builtin_fmaf(p, z, 4.048108837e-04f);
+  p = __builtin_fmaf(p, z, -1.351170171e-03f);
+  p = __builtin_fmaf(p, z, -1.014353406e-03f);
+  p = __builtin_fmaf(p, z, 2.848045249e-02f);
+  p = __builtin_fmaf(p, z, -1.485975645e-01f);
+  p = __builtin_fmaf(p, z, -9.183867066e-01f);
+  p = __builtin_fmaf(p, z, -1.627911755e+00f);
+  p = __builtin_fmaf(p, z, -9.999999142e-01f);
+  return __builtin_fmaf(-fabsf(g), __builtin_amdgcn_exp2f(p), fmaxf(g, 0.f));
 }
 
 // Finish 4 consecutive output channels n0..n0+3 of row m (alpha, bias, per-sample bias, residual) and store them in
