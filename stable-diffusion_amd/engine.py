@@ -408,6 +408,8 @@ def conv3x3(a, weight, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowbias
             optr, ldc = res.ptr, res.ld
     ws, wsb = _workspace(a.device, L.load().sdmi_conv3x3_ws_bytes(a.n, cin, cout, ho, wo))
     ext = None
+    if isinstance(res, Act):
+        res.normed = None               # a caller's `out=` view may be reused: whatever an earlier producer left is stale now
     if isinstance(res, Act) and gno is not None:
         res.stats.pop(res.off, None)
         res.normed = (_gn_key(gn_next[0], gn_next[1], gn_next[2], gn_next[3], groups), gy)
@@ -459,6 +461,7 @@ def gemm(a, wp, n_out, bias=None, residual=None, geglu=False, out=None, out_shap
         flags |= L.F_LNFOLD
         ext = L.EpilogueExt(ln_rowstats=rst.data_ptr(), ln_u=u.data_ptr(), ln_parts=parts, ln_eps=float(eps))
     res.rstats = None
+    res.normed = None
     keep_cs = False
     if (colstats and USE_COLSTATS and a.hw >= 2304) or rowstats:
         rp, cp = ctypes.c_int(0), ctypes.c_int(0)
