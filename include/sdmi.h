@@ -257,6 +257,17 @@ int sdmi_timestep_embedding(const int64_t* t, const float* freqs, float* out, in
 int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,
                    int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq, int nkv,
                    float scale, void* stream);
+/* ---- cross-attention with its query projection inside the kernel: LayerNorm -> to_q -> memory_efficient_attention of
+ *      layers/SpatialTransformer.py:184, :62, :76-95 in ONE launch (the text context's K / V are projected once per prompt).
+ *      x: the UN-normalised token stream (B, nq, c), row stride ldx, batch stride sx; rowstats: [B * nq][parts][2] (sum, sumsq)
+ *      of its rows, left by its producer (sdmi_gemm_ex, ext.rowstats); wq_packed / ln_u / ln_v: to_q through
+ *      sdmi_pack_linear_ln with scale * log2(e) folded into the weights ([heads * 64][c]); k / v / o as sdmi_attention.
+ *      c % 64 == 0.  Not bit-identical to sdmi_gemm_ex(LNFOLD) + sdmi_attention_log2q (another MFMA shape sums K in another
+ *      order): equal to it within the rounding of q. */
+int sdmi_cross_attention_lnq(const void* x, int ldx, int64_t sx, int c, const void* wq_packed, int ldw, const float* ln_u,
+                             const float* ln_v, const float* rowstats, int parts, float eps, const void* k, int ldk, int64_t sk,
+                             const void* v, int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch, int heads, int nq,
+                             int nkv, void* stream);
 /*      Same, for q that already carries scale * log2(e): o = softmax_base2(q k^T) v.  The caller folds the factor into the
  *      query projection's weights before they are rounded to 16 bits (to_q at layers/SpatialTransformer.py:60,78), so the
  *      kernel exponentiates the MFMA result as it stands and q sees no second rounding. */

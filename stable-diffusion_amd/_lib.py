@@ -73,6 +73,7 @@ PROTOTYPES = {
     "sdmi_linear_small_m": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u32, _vp]),
     "sdmi_timestep_embedding": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdmi_attention": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp]),
+    "sdmi_cross_attention_lnq": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "sdmi_inpaint_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sdmi_posterior_sample": (_i, [_vp, _vp, _f, _vp, _i64, _i, _i, _vp]),
     "sdmi_attention_d512": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _f, _vp]),

@@ -20,6 +20,13 @@ struct AttnParams {
   int ldq, ldk, ldv, ldo;
   int nq, nkv, nqt, heads;
   float scale_log2;
+  // fused LayerNorm + to_q projection (attn64_kernel<true>, sdmi_cross_attention_lnq): q is not read; the query rows are
+  // computed from the raw token stream x, the gamma-folded to_q weights and the row statistics x's producer left
+  const u16* x; long long sx; int ldx;      // (B, nq, C) raw tokens
+  const u16* wq; int ldwq;                  // [heads * 64][C], K contiguous (sdmi_pack_linear_ln; scale * log2(e) folded in)
+  const float* lnu; const float* lnv;       // [heads * 64]
+  const float* rstats; int parts; float eps;  // [B * nq][parts][2] (sum, sumsq) of x's rows
+  int C;
 };
 
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -113,6 +120,16 @@ __device__ __forceinline__ void attn_tile(const u16* sK, const u16* sV, const hx
 
 // grid: 1-D, nqt * heads * batch blocks; the XCD remap gives each XCD a contiguous run of (batch, head, q-tile) so
 // the K/V of the (one or two) heads an XCD is working on stay in its 4 MB L2 instead of being re-streamed by 8 XCDs.
+// QPROJ (round 3, sdmi_cross_attention_lnq): the cross-attention's query projection inside the kernel.  The reference runs
+// LayerNorm -> to_q (layers/SpatialTransformer.py:184, :62) in front of every cross-attention: here a GEMM launch of ~10 us for
+// a 128 x 64 x C product per block.  Each wave computes the Q^T tile of its own 32 rows with the same 32x32x16 MFMA it uses for
+// S^T = K Q^T: A = a 32-row slab of the head's weights, B = the wave's token rows straight from global memory (a lane's B
+// fragment is 8 consecutive channels of its row: one 16-byte load).  The weight rows of the two slabs are taken in the order
+// that makes the MFMA result registers of lane (row r, half hh) exactly the B fragments qf[ks] of the score MFMAs
+// (d = 16 ks + 8 hh + e): no lane exchange, no LDS.  The LayerNorm is folded as in the GEMM epilogue (csrc/igemm.hip):
+// q = rstd (acc - mean u[d]) + v[d] with the row's (mean, rstd) from its producer's row statistics, rounded to 16 bits as the
+// stored q would have been.  K / V tile 0 is requested before the projection and lands under it.
+template <bool QPROJ>
 __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
   // double-buffered tile images, one barrier per KV tile.  Four separate arrays, and the loop below is unrolled by two
   // so that every access names its array: the compiler then knows that a fragment read of one buffer cannot alias the
@@ -130,8 +147,10 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
   const int qrow = qt * 128 + wv * 32 + r;
   const int qrc = qrow < p.nq ? qrow : p.nq - 1;
   hx8 qf[4];
+  if constexpr (!QPROJ) {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const hx8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const hx8*)(Q + (long long)qrc * p.ldq + 16 * ks + 8 * hh);
+  }
 
   // staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land on 1 KB of consecutive LDS = 8 tile rows): wave w
   // moves rows [16w, 16w+16) of K and of V with two instructions each; the XOR swizzle of the LDS image is applied on
@@ -174,6 +193,59 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
 
   const int ntiles = (p.nkv + 63) / 64;
   ATTN_STAGE_TILE(0, sK0, sV0);
+  if constexpr (QPROJ) {
+    // ---- row statistics -> (mean, rstd): four interleaved partial sums, finished in double (as the GEMM's LN fold)
+    const float2* sp = (const float2*)p.rstats + ((long long)bz * p.nq + qrc) * p.parts;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pp = 0; pp < p.parts; pp += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float2 v = pp + j < p.parts ? sp[pp + j] : make_float2(0.f, 0.f);
+        a0[j] += v.x; a1[j] += v.y;
+      }
+    }
+    const double inv = 1.0 / (double)p.C;
+    const double mean = (double)((a0[0] + a0[1]) + (a0[2] + a0[3])) * inv;
+    const double var = fmax((double)((a1[0] + a1[1]) + (a1[2] + a1[3])) * inv - mean * mean, 0.0);
+    const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    // ---- Q^T = Wq_h X^T: weight row of A-row m (slab 0; slab 1 = + 32) so that result register i of lane (r, hh) is
+    //      q[r][16 (i >> 3) + 8 hh + (i & 7)] (+ 32 for slab 1)
+    const int dm = 16 * (r >> 4) + 8 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1) + (r & 3);
+    const u16* xr = p.x + (long long)bz * p.sx + (long long)qrc * p.ldx + 8 * hh;
+    const u16* w0 = p.wq + (long long)(head * 64 + dm) * p.ldwq + 8 * hh;
+    const u16* w1 = w0 + (long long)32 * p.ldwq;
+    f32x16 qa[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { qa[0][i] = 0.f; qa[1][i] = 0.f; }
+    hx8 xf[4], wa[4], wb[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { xf[s4] = *(const hx8*)(xr + 16 * s4); wa[s4] = *(const hx8*)(w0 + 16 * s4); wb[s4] = *(const hx8*)(w1 + 16 * s4); }
+    for (int k = 64; k <= p.C; k += 64) {  // C % 64 == 0 (host); fragments of the next 64 channels are in flight under the MFMAs
+      hx8 xn[4], an[4], bn[4];
+      const int kn = k < p.C ? k : 0;      // last round: a harmless reload of the first fragments
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { xn[s4] = *(const hx8*)(xr + kn + 16 * s4); an[s4] = *(const hx8*)(w0 + kn + 16 * s4); bn[s4] = *(const hx8*)(w1 + kn + 16 * s4); }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        qa[0] = MFMA32(wa[s4], xf[s4], qa[0], 0, 0, 0);
+        qa[1] = MFMA32(wb[s4], xf[s4], qa[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { xf[s4] = xn[s4]; wa[s4] = an[s4]; wb[s4] = bn[s4]; }
+    }
+    // ---- LayerNorm fold + rounding: qf[ks][e] = q[r][16 ks + 8 hh + e] = result register 8 (ks & 1) + e of slab ks >> 1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float* up = p.lnu + head * 64 + 16 * ks + 8 * hh;
+      const float* vp = p.lnv + head * 64 + 16 * ks + 8 * hh;
+      const f32x4 u0 = *(const f32x4*)up, u1 = *(const f32x4*)(up + 4), v0 = *(const f32x4*)vp, v1 = *(const f32x4*)(vp + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float uu = e < 4 ? u0[e & 3] : u1[e & 3], vv = e < 4 ? v0[e & 3] : v1[e & 3];
+        qf[ks][e] = f2h16((qa[ks >> 1][8 * (ks & 1) + e] - fmean * uu) * frstd + vv);
+      }
+    }
+  }
   __syncthreads();  // waits for this wave's DMA (vmcnt) before the barrier: tile 0 has landed for everyone
   const int nfull = p.nkv >> 6;  // full tiles run the mask-free instantiation
   // one full tile read from (CK, CV); the other buffer was last read a tile ago and every wave is past that barrier:
@@ -1021,9 +1093,32 @@ static int attention_launch(const void* q, int ldq, int64_t sq, const void* k, i
   }
   p.nqt = (nq + 127) / 128; p.heads = heads;
   dim3 grid(p.nqt * heads * batch), block(256);
-  hipLaunchKernelGGL(attn64_kernel, grid, block, 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn64_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
   sdmi_note_kernel("attn64_kernel");
   return sdmi_check_launch("attention");
+}
+
+extern "C" int sdmi_cross_attention_lnq(const void* x, int ldx, int64_t sx, int c, const void* wq_packed, int ldw, const float* ln_u,
+                                        const float* ln_v, const float* rowstats, int parts, float eps, const void* k, int ldk,
+                                        int64_t sk, const void* v, int ldv, int64_t sv, void* o, int ldo, int64_t so, int batch,
+                                        int heads, int nq, int nkv, void* stream) {
+  SDMI_REQUIRE(x && wq_packed && ln_u && ln_v && rowstats && k && v && o, "cross_attention_lnq: null pointer");
+  SDMI_REQUIRE(batch > 0 && heads > 0 && nq > 0 && nkv > 0 && c > 0 && c % 64 == 0 && parts > 0 && eps > 0.f, "cross_attention_lnq: bad shape (c=%d must be a multiple of 64)", c);
+  SDMI_REQUIRE(ldx % 8 == 0 && ldx >= c && ldw % 8 == 0 && ldw >= c && sx % 8 == 0, "cross_attention_lnq: x / weight strides");
+  SDMI_REQUIRE(ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && ldk >= heads * 64 && ldv >= heads * 64 && ldo >= heads * 64, "cross_attention_lnq: k / v / o strides");
+  SDMI_REQUIRE((((uintptr_t)x | (uintptr_t)wq_packed | (uintptr_t)k | (uintptr_t)v | (uintptr_t)ln_u | (uintptr_t)ln_v) & 15) == 0 &&
+                   (((uintptr_t)o | (uintptr_t)rowstats) & 7) == 0, "cross_attention_lnq: pointer alignment");
+  SDMI_REQUIRE(sk % 8 == 0 && sv % 8 == 0 && so % 4 == 0 && ldk < (1 << 22) && ldv < (1 << 22), "cross_attention_lnq: k / v strides");
+  SDMI_REQUIRE((long long)((nq + 127) / 128) * heads * batch < (1ll << 31), "cross_attention_lnq: grid too large");
+  AttnParams p = {};
+  p.q = nullptr; p.k = (const u16*)k; p.v = (const u16*)v; p.o = (u16*)o;
+  p.sq = 0; p.sk = sk; p.sv = sv; p.so = so; p.ldq = 0; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.nq = nq; p.nkv = nkv; p.scale_log2 = 1.0f; p.nqt = (nq + 127) / 128; p.heads = heads;
+  p.x = (const u16*)x; p.sx = sx; p.ldx = ldx; p.wq = (const u16*)wq_packed; p.ldwq = ldw; p.lnu = ln_u; p.lnv = ln_v;
+  p.rstats = rowstats; p.parts = parts; p.eps = eps; p.C = c;
+  hipLaunchKernelGGL(attn64_kernel<true>, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
+  sdmi_note_kernel("attn64_kernel<true>");
+  return sdmi_check_launch("cross attention with query projection");
 }
 
 extern "C" int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k, int ldk, int64_t sk, const void* v,

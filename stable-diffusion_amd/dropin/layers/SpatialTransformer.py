@@ -119,14 +119,18 @@ class MemoryEfficientCrossAttention(nn.Module):
                                     "fails in to_k as well)" % (self.to_k.weight.shape[1], a.c))
             qkv = proj((self.to_q.weight, self.to_k.weight, self.to_v.weight))
             q, k, v = qkv.cols(0, inner), qkv.cols(inner, inner), qkv.cols(2 * inner, inner)
+            o = None
         else:
-            q = proj((self.to_q.weight,))
             if isinstance(context, ContextKV):
                 kv = context.kv[id(self)]
             else:
                 kv = E.gemm(context, E.packed_linear((self.to_k.weight, self.to_v.weight)), 2 * inner)
             k, v = kv.cols(0, inner), kv.cols(inner, inner)
-        o = E.attention(q, k, v, self.heads, log2q=True)
+            # LayerNorm + to_q inside the attention kernel where the engine offers it (one launch less)
+            o = E.cross_attention_lnq(a, ln, self.to_q.weight, k, v, self.heads) if ln is not None else None
+            q = proj((self.to_q.weight,)) if o is None else None
+        if o is None:
+            o = E.attention(q, k, v, self.heads, log2q=True)
         lin = self.to_out[0]
         return E.gemm(o, E.packed_linear((lin.weight,)), lin.weight.shape[0], bias=lin.bias, residual=residual, rowstats=rowstats)
 

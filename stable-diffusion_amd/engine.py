@@ -547,6 +547,28 @@ def attention(q, k, v, heads, out=None, log2q=False):
     return o
 
 
+# cross-attention with its LayerNorm + to_q projection inside the attention kernel (sdmi_cross_attention_lnq): one launch
+# less per cross-attention.  XATTN_FUSE_Q_MAX_C: widest token stream it is used for (the kernel reads the head's weights from
+# global memory in every wave: wide streams are better served by the GEMM); 0 = never
+XATTN_FUSE_Q_MAX_C = int(os.environ.get("SDMI_XATTN_FUSE_Q_MAX_C", "0"))
+
+
+def cross_attention_lnq(a, ln_mod, to_q_weight, k, v, heads, out=None):
+    """softmax(to_q(LayerNorm(a)) k^T / 8) v per head in ONE launch; None when this call cannot take the fused kernel (the
+    caller then runs gemm_ln + attention).  `a` must carry row statistics (gemm(..., rowstats=True))."""
+    if not (USE_LNFOLD and a.rstats is not None and a.c % 64 == 0 and 0 < a.c <= XATTN_FUSE_Q_MAX_C):
+        return None
+    wp, u, vv = packed_linear_ln((to_q_weight,), ln_mod.weight, ln_mod.bias, None, False, (Q_LOG2_SCALE,))
+    rst, parts = a.rstats
+    o = out if out is not None else new_act(a.n, a.h, a.w, heads * 64, a.device)
+    if (o.n, o.hw, o.c) != (a.n, a.hw, heads * 64) or (k.n, v.n, v.hw) != (a.n, a.n, k.hw) or wp.shape[0] != heads * 64:
+        raise L.SdmiError("cross_attention_lnq: shapes do not match")
+    L.call("sdmi_cross_attention_lnq", a.ptr, a.ld, a.hw * a.ld, a.c, wp.data_ptr(), wp.shape[1], u.data_ptr(), vv.data_ptr(),
+           rst.data_ptr(), parts, float(ln_mod.eps), k.ptr, k.ld, k.hw * k.ld, v.ptr, v.ld, v.hw * v.ld, o.ptr, o.ld, o.hw * o.ld,
+           a.n, heads, a.hw, k.hw, _stream())
+    return o
+
+
 def linear_small_m(x, wp, bias, silu_in=False):
     """fp32 (M<=64, K) x bf16 [N][K] -> fp32 (M, N)."""
     x = x.contiguous()

@@ -653,3 +653,48 @@ def test_upsample_conv_on_window_kernel_bit_identical(n, hh, ww, c, cout):
         ref = F.conv2d(F.pad(F.interpolate(xf, scale_factor=2.0, mode="nearest"), (1, 1, 1, 1)), W, B).permute(0, 2, 3, 1).reshape(n, 4 * hh * ww, cout)
     err = float((got[0].float() - ref).norm() / ref.norm())
     assert err < 6e-4 * _tol(), err
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Cross-attention with LayerNorm + to_q inside the attention kernel (sdmi_cross_attention_lnq, attn64_kernel<true>): against
+# the two-launch path (LN-folded GEMM + attention) and against the fp64 definition; ragged row counts, several samples.
+@pytest.mark.parametrize("n,nq,c,heads,nkv", [(1, 9216, 320, 5, 77), (2, 2304, 640, 10, 77), (1, 576, 1280, 20, 77),
+                                               (3, 200, 320, 5, 77), (1, 144, 1280, 20, 130)])
+def test_cross_attention_with_fused_query_projection(n, nq, c, heads, nkv):
+    lib = L.load()
+    rs = np.random.RandomState(nq + c)
+    H = E.act_dtype()
+    inner = 64 * heads
+    x0 = E.Act(T((rs.randn(n, nq, c) * 1.3 + 0.4).astype(np.float32)).to(DEV).to(H), n, 1, nq, c)
+    w0 = (T((np.eye(c) + 0.05 * rs.randn(c, c)).astype(np.float32))).to(DEV).to(H).contiguous()
+    a = E.gemm(x0, w0, c, rowstats=True)                       # a producer that leaves row statistics
+    assert a.rstats is not None
+    ln = torch.nn.LayerNorm(c).to(DEV)
+    ln.weight.data = T((1.0 + 0.3 * rs.randn(c)).astype(np.float32)).to(DEV)
+    ln.bias.data = T((0.2 * rs.randn(c)).astype(np.float32)).to(DEV)
+    Wq = torch.nn.Parameter(T((rs.randn(inner, c) / np.sqrt(c)).astype(np.float32)).to(DEV))
+    kv = E.Act(T(rs.randn(n, nkv, 2 * inner).astype(np.float32)).to(DEV).to(H), n, 1, nkv, 2 * inner)
+    k, v = kv.cols(0, inner), kv.cols(inner, inner)
+    saved = E.XATTN_FUSE_Q_MAX_C
+    try:
+        E.XATTN_FUSE_Q_MAX_C = 4096
+        o1 = E.cross_attention_lnq(a, ln, Wq, k, v, heads)
+        assert o1 is not None and lib.sdmi_last_kernel().decode() == "attn64_kernel<true>"
+        E.XATTN_FUSE_Q_MAX_C = 0
+        assert E.cross_attention_lnq(a, ln, Wq, k, v, heads) is None
+    finally:
+        E.XATTN_FUSE_Q_MAX_C = saved
+    q = E.gemm_ln(a, ln, (Wq,), scales=(E.Q_LOG2_SCALE,))
+    o2 = E.attention(q, k, v, heads, log2q=True)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        xa = a.buf.double()
+        qd = torch.nn.functional.layer_norm(xa, (c,), ln.weight.double(), ln.bias.double(), ln.eps) @ Wq.double().t()
+        sp = lambda t_: t_.double().reshape(n, t_.shape[1], heads, 64).permute(0, 2, 1, 3)
+        kk, vv_ = kv.buf[:, :, :inner], kv.buf[:, :, inner:]
+        ref = (torch.softmax(sp(qd) @ sp(kk).transpose(-1, -2) * 0.125, dim=-1) @ sp(vv_)).permute(0, 2, 1, 3).reshape(n, nq, inner)
+    e1 = float((o1.buf.double() - ref).norm() / ref.norm())
+    e2 = float((o2.buf.double() - ref).norm() / ref.norm())
+    d12 = float((o1.buf.double() - o2.buf.double()).norm() / ref.norm())
+    print("fused vs fp64 %.2e, two launches vs fp64 %.2e, fused vs two launches %.2e" % (e1, e2, d12))
+    assert e1 < 6e-4 * _tol() and e1 < 1.3 * e2 + 5e-5
