@@ -262,7 +262,7 @@ int sdmi_attention(const void* q, int ldq, int64_t sq, const void* k, int ldk, i
  *      x: the UN-normalised token stream (B, nq, c), row stride ldx, batch stride sx; rowstats: [B * nq][parts][2] (sum, sumsq)
  *      of its rows, left by its producer (sdmi_gemm_ex, ext.rowstats); wq_packed / ln_u / ln_v: to_q through
  *      sdmi_pack_linear_ln with scale * log2(e) folded into the weights ([heads * 64][c]); k / v / o as sdmi_attention.
- *      c % 64 == 0.  Not bit-identical to sdmi_gemm_ex(LNFOLD) + sdmi_attention_log2q (another MFMA shape sums K in another
+ *      c = 320 or 640 (the head's 64 weight rows are staged whole in the LDS).  Not bit-identical to sdmi_gemm_ex(LNFOLD) + sdmi_attention_log2q (another MFMA shape sums K in another
  *      order): equal to it within the rounding of q. */
 int sdmi_cross_attention_lnq(const void* x, int ldx, int64_t sx, int c, const void* wq_packed, int ldw, const float* ln_u,
                              const float* ln_v, const float* rowstats, int parts, float eps, const void* k, int ldk, int64_t sk,

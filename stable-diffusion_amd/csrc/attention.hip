@@ -193,7 +193,29 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
 
   const int ntiles = (p.nkv + 63) / 64;
   ATTN_STAGE_TILE(0, sK0, sV0);
+  extern __shared__ __attribute__((aligned(16))) u16 dynW[];  // QPROJ: the head's 64 weight rows, C / 8 + 1 slots of 16 B per row
+  [[maybe_unused]] const int wslots = p.C / 8 + 1;             // (the odd slot count keeps a 16-lane fragment read on 16 distinct slots)
   if constexpr (QPROJ) {
+    {
+      const int total = 64 * wslots;
+      const u16* wsrc = p.wq + (long long)head * 64 * p.ldwq;
+      for (int base = 0; base < total; base += 256) {
+        const int pc = min(base + t, total - 1);
+        const int row = pc / wslots, piece = min(pc - row * wslots, wslots - 2);   // the pad slot re-fetches the last piece
+        ATTN_GLDS(wsrc + (long long)row * p.ldwq + piece * 8, &dynW[(base + __builtin_amdgcn_readfirstlane(wv) * 64) * 8]);
+      }
+    }
+    // ---- Q^T = Wq_h X^T: weight row of A-row m (slab 0; slab 1 = + 32) so that result register i of lane (r, hh) is
+    //      q[r][16 (i >> 3) + 8 hh + (i & 7)] (+ 32 for slab 1)
+    const int dm = 16 * (r >> 4) + 8 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1) + (r & 3);
+    const u16* xr = p.x + (long long)bz * p.sx + (long long)qrc * p.ldx + 8 * hh;
+    // the row's channels in chunks of 320 (20 fragments in flight at once: one memory latency per chunk)
+    hx8 xf[20];
+#pragma unroll
+    for (int s4 = 0; s4 < 20; ++s4) xf[s4] = *(const hx8*)(xr + 16 * s4);
+    f32x16 qa[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { qa[0][i] = 0.f; qa[1][i] = 0.f; }
     // ---- row statistics -> (mean, rstd): four interleaved partial sums, finished in double (as the GEMM's LN fold)
     const float2* sp = (const float2*)p.rstats + ((long long)bz * p.nq + qrc) * p.parts;
     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -208,30 +230,20 @@ __global__ __launch_bounds__(256, 3) void attn64_kernel(const AttnParams p) {
     const double mean = (double)((a0[0] + a0[1]) + (a0[2] + a0[3])) * inv;
     const double var = fmax((double)((a1[0] + a1[1]) + (a1[2] + a1[3])) * inv - mean * mean, 0.0);
     const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    // ---- Q^T = Wq_h X^T: weight row of A-row m (slab 0; slab 1 = + 32) so that result register i of lane (r, hh) is
-    //      q[r][16 (i >> 3) + 8 hh + (i & 7)] (+ 32 for slab 1)
-    const int dm = 16 * (r >> 4) + 8 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1) + (r & 3);
-    const u16* xr = p.x + (long long)bz * p.sx + (long long)qrc * p.ldx + 8 * hh;
-    const u16* w0 = p.wq + (long long)(head * 64 + dm) * p.ldwq + 8 * hh;
-    const u16* w1 = w0 + (long long)32 * p.ldwq;
-    f32x16 qa[2];
+    __syncthreads();  // the head's weights (DMA above) have landed for every wave
+    const u16* wl0 = dynW + (dm * wslots + hh) * 8;
+    const u16* wl1 = wl0 + 32 * wslots * 8;
+    for (int cb = 0; cb < p.C; cb += 320) {
+      if (cb > 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { qa[0][i] = 0.f; qa[1][i] = 0.f; }
-    hx8 xf[4], wa[4], wb[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) { xf[s4] = *(const hx8*)(xr + 16 * s4); wa[s4] = *(const hx8*)(w0 + 16 * s4); wb[s4] = *(const hx8*)(w1 + 16 * s4); }
-    for (int k = 64; k <= p.C; k += 64) {  // C % 64 == 0 (host); fragments of the next 64 channels are in flight under the MFMAs
-      hx8 xn[4], an[4], bn[4];
-      const int kn = k < p.C ? k : 0;      // last round: a harmless reload of the first fragments
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { xn[s4] = *(const hx8*)(xr + kn + 16 * s4); an[s4] = *(const hx8*)(w0 + kn + 16 * s4); bn[s4] = *(const hx8*)(w1 + kn + 16 * s4); }
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        qa[0] = MFMA32(wa[s4], xf[s4], qa[0], 0, 0, 0);
-        qa[1] = MFMA32(wb[s4], xf[s4], qa[1], 0, 0, 0);
+        for (int s4 = 0; s4 < 20; ++s4) xf[s4] = *(const hx8*)(xr + cb + 16 * s4);
       }
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { xf[s4] = xn[s4]; wa[s4] = an[s4]; wb[s4] = bn[s4]; }
+      for (int s4 = 0; s4 < 20; ++s4) {
+        const hx8 wa = *(const hx8*)(wl0 + (cb + 16 * s4) ), wb = *(const hx8*)(wl1 + (cb + 16 * s4));
+        qa[0] = MFMA32(wa, xf[s4], qa[0], 0, 0, 0);
+        qa[1] = MFMA32(wb, xf[s4], qa[1], 0, 0, 0);
+      }
     }
     // ---- LayerNorm fold + rounding: qf[ks][e] = q[r][16 ks + 8 hh + e] = result register 8 (ks & 1) + e of slab ks >> 1
 #pragma unroll
@@ -1116,7 +1128,18 @@ extern "C" int sdmi_cross_attention_lnq(const void* x, int ldx, int64_t sx, int 
   p.nq = nq; p.nkv = nkv; p.scale_log2 = 1.0f; p.nqt = (nq + 127) / 128; p.heads = heads;
   p.x = (const u16*)x; p.sx = sx; p.ldx = ldx; p.wq = (const u16*)wq_packed; p.ldwq = ldw; p.lnu = ln_u; p.lnv = ln_v;
   p.rstats = rowstats; p.parts = parts; p.eps = eps; p.C = c;
-  hipLaunchKernelGGL(attn64_kernel<true>, dim3(p.nqt * heads * batch), dim3(256), 0, (hipStream_t)stream, p);
+  SDMI_REQUIRE(c % 320 == 0 && c <= 640, "cross_attention_lnq: c must be 320 or 640 (the head's weights are staged whole in the LDS; wider streams: LN-folded GEMM + sdmi_attention_log2q)");
+  const int lds = ((64 * (c / 8 + 1) + 255) / 256) * 256 * 16;
+  {
+    static unsigned long long attr_done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+      (void)hipFuncSetAttribute((const void*)attn64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_done |= 1ull << (dev & 63);
+    }
+  }
+  hipLaunchKernelGGL(attn64_kernel<true>, dim3(p.nqt * heads * batch), dim3(256), lds, (hipStream_t)stream, p);
   sdmi_note_kernel("attn64_kernel<true>");
   return sdmi_check_launch("cross attention with query projection");
 }

@@ -548,15 +548,15 @@ def attention(q, k, v, heads, out=None, log2q=False):
 
 
 # cross-attention with its LayerNorm + to_q projection inside the attention kernel (sdmi_cross_attention_lnq): one launch
-# less per cross-attention.  XATTN_FUSE_Q_MAX_C: widest token stream it is used for (the kernel reads the head's weights from
-# global memory in every wave: wide streams are better served by the GEMM); 0 = never
+# less per cross-attention.  XATTN_FUSE_Q_MAX_C: widest token stream it is used for (the kernel stages the head's weights in the
+# LDS whole: 320 or 640 channels); 0 = never
 XATTN_FUSE_Q_MAX_C = int(os.environ.get("SDMI_XATTN_FUSE_Q_MAX_C", "0"))
 
 
 def cross_attention_lnq(a, ln_mod, to_q_weight, k, v, heads, out=None):
     """softmax(to_q(LayerNorm(a)) k^T / 8) v per head in ONE launch; None when this call cannot take the fused kernel (the
     caller then runs gemm_ln + attention).  `a` must carry row statistics (gemm(..., rowstats=True))."""
-    if not (USE_LNFOLD and a.rstats is not None and a.c % 64 == 0 and 0 < a.c <= XATTN_FUSE_Q_MAX_C):
+    if not (USE_LNFOLD and a.rstats is not None and a.c in (320, 640) and a.c <= XATTN_FUSE_Q_MAX_C):
         return None
     wp, u, vv = packed_linear_ln((to_q_weight,), ln_mod.weight, ln_mod.bias, None, False, (Q_LOG2_SCALE,))
     rst, parts = a.rstats
