@@ -7,7 +7,8 @@ Parameter names are open_clip's (`token_embedding.weight`, `positional_embedding
 attn.in_proj_weight / attn.in_proj_bias / attn.out_proj / ln_2 / mlp.c_fc / mlp.c_proj`, `ln_final`, `text_projection`,
 `logit_scale`), so the `cond_stage_model.*` entries of the reference's checkpoint remap (:257) load with
 load_state_dict().  open_clip itself (mlfoundations/open_clip, version not pinned by the reference) and its BPE vocabulary
-are not in this image: callers pass token ids (what `open_clip.tokenize` returns), and parity is against the oracle's
+are not in this image: callers pass token ids (what `open_clip.tokenize` returns) or text plus the vocabulary file
+(stable_diffusion_amd/tokenizer.py restates the BPE tokenizer), and parity is against the oracle's
 restatement of the published block (clip_text_encode in the test oracle) - parity unpinned, see DESIGN.md."""
 import torch
 from torch import nn
@@ -84,10 +85,15 @@ class ClipTextEncoder(nn.Module):
         self.register_buffer("attn_mask", mask, persistent=False)           # the kernel applies it as "keys 0..i"
 
     @torch.no_grad()
-    def get_conditional(self, tokens):
-        """tokens: LongTensor (B, context_length) of BPE ids (open_clip.tokenize's output).  Returns (B, T, width) fp32:
-        ln_final of the penultimate block's output, as the reference computes it (:236-245)."""
+    def get_conditional(self, tokens, tokenizer=None):
+        """tokens: LongTensor (B, context_length) of BPE ids (open_clip.tokenize's output), or - as the reference's
+        get_conditional(text) takes it (:232-233) - a string / list of strings, tokenized on the host by
+        stable_diffusion_amd.tokenizer (needs the CLIP BPE vocabulary file: `tokenizer=` or env SDMI_CLIP_BPE).  Returns
+        (B, T, width) fp32: ln_final of the penultimate block's output, as the reference computes it (:236-245)."""
         dev = self.positional_embedding.device
+        if isinstance(tokens, str) or (isinstance(tokens, (list, tuple)) and tokens and isinstance(tokens[0], str)):
+            from . import tokenizer as TK
+            tokens = TK.tokenize(tokens, self.context_length, tokenizer)
         tokens = torch.as_tensor(tokens, dtype=torch.long, device=dev).contiguous()
         if tokens.dim() != 2 or tokens.shape[1] != self.context_length:
             raise L.SdmiError("get_conditional: tokens must be (B, %d), got %s" % (self.context_length, tuple(tokens.shape)))
