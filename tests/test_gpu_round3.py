@@ -698,3 +698,24 @@ def test_cross_attention_with_fused_query_projection(n, nq, c, heads, nkv):
     d12 = float((o1.buf.double() - o2.buf.double()).norm() / ref.norm())
     print("fused vs fp64 %.2e, two launches vs fp64 %.2e, fused vs two launches %.2e" % (e1, e2, d12))
     assert e1 < 6e-4 * _tol() and e1 < 1.3 * e2 + 5e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# get_conditional(text): the host tokenizer in front of the HIP text tower (synthetic merge table: the CLIP vocabulary file
+# is not in the image) gives what get_conditional(ids) gives.
+def test_get_conditional_accepts_text(tmp_path):
+    import gzip
+    from stable_diffusion_amd import tokenizer as TK
+    from stable_diffusion_amd.clip_text import ClipTextEncoder
+    merges = ["l o", "lo w</w>", "e r</w>", "a n", "an d</w>"]
+    p = tmp_path / "bpe.txt.gz"
+    with gzip.open(p, "wb") as f:
+        f.write(("#version: synthetic\n" + "\n".join(merges) + "\n").encode("utf-8"))
+    tok = TK.SimpleTokenizer(str(p), vocab_size=512 + len(merges) + 2)
+    m = ClipTextEncoder(vocab_size=512 + len(merges) + 2, context_length=77, width=128, heads=2, layers=3)
+    fill_state_dict(m.state_dict(), seed=4, fast=True)
+    m = m.to(DEV).eval()
+    texts = ["low and lower", "LOWER   low"]
+    a = m.get_conditional(texts, tokenizer=tok)
+    b = m.get_conditional(TK.tokenize(texts, tokenizer=tok))
+    assert a.shape == (2, 77, 128) and torch.isfinite(a).all() and torch.equal(a, b)
