@@ -52,6 +52,8 @@ def work_of(name, a):
         return 4.0 * b * h * nq * nk * 64, 2.0 * b * h * 64 * (2 * nq + 2 * nk)
     if name == "sdmi_groupnorm":
         return 0.0, 4.0 * a[4] * a[5] * a[6]
+    if name == "sdmi_groupnorm_from_colstats":      # fold of the producer's statistics + apply: the tensor read once, written once
+        return 0.0, 4.0 * a[4] * a[5] * a[6]
     if name == "sdmi_groupnorm_stats":
         return 0.0, 2.0 * a[1] * a[2] * a[3]
     if name == "sdmi_groupnorm_apply":
