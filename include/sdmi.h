@@ -129,6 +129,10 @@ int sdmi_ws_tickets_release(void* ws);
  *      Unet.py:49 (9->320), AutoencoderKL.py:136 (4->512), :61 (3->128).  w is the fp32 OIHW weight. */
 int sdmi_conv3x3_in(const float* x_nchw, int n, int cin, int h, int w, const float* w_oihw, const float* bias,
                     int cout, void* out, int ldc, void* stream);
+/* the same, also leaving colstats fp32 [n * h * w / 32][cout][2] (per-channel sum / sum of squares of every 32-pixel part, as
+ * sdmi_epilogue_ext.colstats) for the GroupNorm that follows (Unet.py:49 -> layers/ResBlock.py:65); h * w % 64 == 0; NULL = none */
+int sdmi_conv3x3_in_ex(const float* x_nchw, int n, int cin, int h, int w, const float* w_oihw, const float* bias,
+                       int cout, void* out, int ldc, float* colstats, void* stream);
 
 /* ---- GEMM out[M][N] = A[M][K] * W[N][K]^T (+epilogue): nn.Linear and 1x1 nn.Conv2d at
  *      layers/SpatialTransformer.py:22-26 (GEGLU), :62-66, :110-129, :199, :204; layers/ResBlock.py:62;

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "sdmi_conv3x3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _u32, _vp, _i64, _vp]),
     "sdmi_conv3x3_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "sdmi_conv3x3_in": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "sdmi_conv3x3_in_ex": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "sdmi_gemm": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp, _i64, _vp]),
     "sdmi_gemm_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _u32]),
     "sdmi_gemm_ex": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _f, _u32, _vp, _i64, _vp, _vp]),

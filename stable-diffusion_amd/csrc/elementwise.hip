@@ -146,10 +146,13 @@ extern "C" int sdmi_pack_linear_ln(const float* w, const float* gamma, const flo
 // x NCHW fp32 (the caller's tensor), w OIHW fp32, out NHWC h16.  lane = pixel (64 consecutive pixels per wave: coalesced
 // NCHW reads), wave = group of 8 output channels: the weight index is wave-uniform, so the 8 x 9*CIN weights arrive
 // through scalar loads and every FMA takes its weight from an SGPR; the 9*CIN input taps sit in registers.
+// colstats (may be null; host: h * w % 64 == 0): per-channel (sum, sumsq) of the fp32 results over each 32-pixel part, the
+// layout the conv / GEMM epilogues of csrc/igemm.hip leave for sdmi_groupnorm_from_colstats: the GroupNorms that read this
+// conv's output (the first ResBlock's norm1 and, through the skip connection, the last output block's) skip their statistics pass.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, u16* __restrict__ out, int h,
-                                                         int wd, int cout, int ldc) {
+                                                         int wd, int cout, int ldc, float* __restrict__ colstats) {
   const int n = blockIdx.z;
   const int hw = h * wd;
   const int pix = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -180,18 +183,33 @@ __global__ __launch_bounds__(256) void conv3x3_in_kernel(const float* __restrict
   u16* op = out + ((long long)n * hw + pix) * ldc + cg * 8;
   if (cg * 8 + 7 < cout) *(uint4*)op = pack8(o);
   else for (int e = 0; e < 8; ++e) if (cg * 8 + e < cout) op[e] = f2h(o[e]);
+  if (colstats) {  // every lane of the wave is live here (h * w % 64 == 0): sums over the 32 lanes of each half, fixed order
+    const long long part = ((long long)n * hw + pix) >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float sm = o[e], sq = o[e] * o[e];
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) { sm += __shfl_xor(sm, d); sq += __shfl_xor(sq, d); }
+      if ((threadIdx.x & 31) == 0 && cg * 8 + e < cout) *(float2*)(colstats + (part * cout + cg * 8 + e) * 2) = make_float2(sm, sq);
+    }
+  }
 }
 extern "C" int sdmi_conv3x3_in(const float* x_nchw, int n, int cin, int h, int w, const float* w_oihw, const float* bias,
                                int cout, void* out, int ldc, void* stream) {
+  return sdmi_conv3x3_in_ex(x_nchw, n, cin, h, w, w_oihw, bias, cout, out, ldc, nullptr, stream);
+}
+extern "C" int sdmi_conv3x3_in_ex(const float* x_nchw, int n, int cin, int h, int w, const float* w_oihw, const float* bias,
+                                  int cout, void* out, int ldc, float* colstats, void* stream) {
   SDMI_REQUIRE(x_nchw && w_oihw && bias && out, "conv3x3_in: null pointer");
+  SDMI_REQUIRE(!colstats || ((h * w) % 64 == 0 && ((uintptr_t)colstats & 7) == 0), "conv3x3_in: colstats need h * w %% 64 == 0 and an 8-byte aligned buffer");
   SDMI_REQUIRE(n > 0 && h > 0 && w > 0 && cout > 0 && n <= 65535, "conv3x3_in: bad shape");
   SDMI_REQUIRE(ldc % 8 == 0 && ldc >= cout && ((uintptr_t)out & 15) == 0, "conv3x3_in: ldc/alignment");
   dim3 grid((h * w + 63) / 64, ((cout + 7) / 8 + 3) / 4, n), block(256);
   hipStream_t st = (hipStream_t)stream;
   switch (cin) {
-    case 3: hipLaunchKernelGGL(conv3x3_in_kernel<3>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc); break;
-    case 4: hipLaunchKernelGGL(conv3x3_in_kernel<4>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc); break;
-    case 9: hipLaunchKernelGGL(conv3x3_in_kernel<9>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc); break;
+    case 3: hipLaunchKernelGGL(conv3x3_in_kernel<3>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc, colstats); break;
+    case 4: hipLaunchKernelGGL(conv3x3_in_kernel<4>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc, colstats); break;
+    case 9: hipLaunchKernelGGL(conv3x3_in_kernel<9>, grid, block, 0, st, x_nchw, w_oihw, bias, (u16*)out, h, w, cout, ldc, colstats); break;
     default: sdmi_set_error("conv3x3_in: cin=%d unsupported (3, 4, 9)", cin); return SDMI_EINVAL;
   }
   return sdmi_check_launch("conv3x3_in");

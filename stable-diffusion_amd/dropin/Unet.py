@@ -196,8 +196,15 @@ class Unet(nn.Module):
         blk = self.input_blocks[0]
         assert isinstance(blk, nn.Conv2d)
         dst = st.cat[0].cols(st.cat[0].c - skip_c[0], skip_c[0])
-        E.L.call("sdmi_conv3x3_in", x.data_ptr(), n, x.shape[1], hh, ww, blk.weight.data_ptr(), blk.bias.data_ptr(),
-                 blk.out_channels, dst.ptr, dst.ld, E._stream())
+        cs = None
+        if E.USE_COLSTATS and E.CONV_IN_COLSTATS and (hh * ww) % 64 == 0 and hh * ww >= 2304:
+            # per-channel statistics for the two GroupNorms that read this tensor (first ResBlock; last output block via the skip)
+            cs = torch.empty((n * hh * ww // 32, blk.out_channels, 2), dtype=torch.float32, device=dev)
+            dst.stats[dst.off] = (cs, hh * ww // 32, blk.out_channels)
+        else:
+            dst.stats.pop(dst.off, None)
+        E.L.call("sdmi_conv3x3_in_ex", x.data_ptr(), n, x.shape[1], hh, ww, blk.weight.data_ptr(), blk.bias.data_ptr(),
+                 blk.out_channels, dst.ptr, dst.ld, E._ptr(cs), E._stream())
         st.h = dst
         st.a1 = st.t1 = None
         return st

@@ -257,6 +257,7 @@ USE_COLSTATS = os.environ.get("SDMI_COLSTATS", "1") == "1"     # GroupNorm stati
 USE_LNFOLD = os.environ.get("SDMI_LNFOLD", "1") == "1"         # LayerNorm folded into the GEMM that follows it (A/B switch)
 # GroupNorm + SiLU applied by the consuming conv to its staged input (north-star item (b)); only convs whose one block column
 # covers every output channel qualify (the VAE's 128-channel level).  Default from the measurement in DESIGN.md section 5.
+CONV_IN_COLSTATS = os.environ.get("SDMI_CONV_IN_COLSTATS", "1") == "1"   # the UNet's first conv leaves GroupNorm statistics too (A/B switch)
 GN_IN_CONV = os.environ.get("SDMI_GN_IN_CONV", "0") == "1"
 # the split-K reduce of a conv also writes the GroupNorm that follows it (24x24 / 12x12 levels).  Off: bit-identical and measured
 # SLOWER (captured step 7.81 -> 7.86 ms; per pair 40 -> 45 us at 24x24, 28.6 -> 29.8 at 12x12: one block per (sample, group) pulls

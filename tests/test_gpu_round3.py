@@ -719,3 +719,29 @@ def test_get_conditional_accepts_text(tmp_path):
     a = m.get_conditional(texts, tokenizer=tok)
     b = m.get_conditional(TK.tokenize(texts, tokenizer=tok))
     assert a.shape == (2, 77, 128) and torch.isfinite(a).all() and torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# conv_in (sdmi_conv3x3_in_ex) leaves the column statistics of its result for the GroupNorms that read it.
+@pytest.mark.parametrize("n,cin,hh,ww,cout", [(2, 9, 48, 48, 320), (1, 4, 96, 32, 512), (1, 3, 64, 64, 128)])
+def test_conv_in_colstats(n, cin, hh, ww, cout):
+    rs = np.random.RandomState(cin + hh)
+    x = T(rs.randn(n, cin, hh, ww).astype(np.float32)).to(DEV)
+    W = T((rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)).to(DEV)
+    B = T(rs.randn(cout).astype(np.float32)).to(DEV)
+    hw = hh * ww
+    pad = 1024
+    cs = torch.full((n * hw // 32 * cout * 2 + pad,), 777.0, dtype=torch.float32, device=DEV)
+    out = torch.zeros((n, hw, cout), dtype=E.act_dtype(), device=DEV)
+    out0 = torch.zeros_like(out)
+    L.call("sdmi_conv3x3_in_ex", x.data_ptr(), n, cin, hh, ww, W.data_ptr(), B.data_ptr(), cout, out.data_ptr(), cout, cs.data_ptr(), E._stream())
+    L.call("sdmi_conv3x3_in", x.data_ptr(), n, cin, hh, ww, W.data_ptr(), B.data_ptr(), cout, out0.data_ptr(), cout, E._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out0)
+    assert bool((cs[-pad:] == 777.0).all())
+    got = cs[:-pad].reshape(n * hw // 32, cout, 2)
+    ref = torch.nn.functional.conv2d(x, W, B, padding=1).permute(0, 2, 3, 1).reshape(n * hw // 32, 32, cout)
+    assert float((got[..., 0] - ref.sum(1)).abs().max()) < 2e-3
+    assert float(((got[..., 1] - (ref * ref).sum(1)).abs() / (ref * ref).sum(1).clamp_min(1.0)).max()) < 1e-4
+    with pytest.raises(L.SdmiError, match="colstats"):
+        L.call("sdmi_conv3x3_in_ex", x.data_ptr(), n, cin, 5, 5, W.data_ptr(), B.data_ptr(), cout, out.data_ptr(), cout, cs.data_ptr(), E._stream())
