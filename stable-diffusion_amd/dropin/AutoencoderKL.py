@@ -46,8 +46,12 @@ def _conv_in(x, conv):
     x = x.contiguous().float()
     n, c, h, w = x.shape
     a = E.new_act(n, h, w, conv.out_channels, x.device)
-    E.L.call("sdmi_conv3x3_in", x.data_ptr(), n, c, h, w, conv.weight.data_ptr(), conv.bias.data_ptr(), conv.out_channels,
-             a.ptr, a.ld, E._stream())
+    cs = None
+    if E.USE_COLSTATS and E.CONV_IN_COLSTATS and (h * w) % 64 == 0 and h * w >= 2304:
+        cs = torch.empty((n * h * w // 32, conv.out_channels, 2), dtype=torch.float32, device=x.device)   # for the GroupNorm that follows
+        a.stats[a.off] = (cs, h * w // 32, conv.out_channels)
+    E.L.call("sdmi_conv3x3_in_ex", x.data_ptr(), n, c, h, w, conv.weight.data_ptr(), conv.bias.data_ptr(), conv.out_channels,
+             a.ptr, a.ld, E._ptr(cs), E._stream())
     E._audit("conv_in %d->%d @%dx%d" % (c, conv.out_channels, h, w), a)
     return a
 
